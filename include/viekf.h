@@ -1,0 +1,150 @@
+/*
+ * viekf.h -- C ABI of the MI355X-native batched VI-EKF core (libviekf_hip.so).
+ *
+ * The reference has no C ABI or plugin registry: its boundary is the C++ class
+ * vi_ekf::VIEKF (reference include/vi_ekf.h:82-338).  Every entry point below
+ * names the VIEKF member it replaces (file:line relative to the reference
+ * tree).  One viekf_batch holds `batch` independent filters that share one
+ * parameter set and one capacity `num_features` (the reference's compile-time
+ * NUM_FEATURES, include/vi_ekf.h:39-48, is a run-time value here):
+ *     nx = 17 + 5*num_features   (MAX_X)      n = 16 + 3*num_features  (MAX_DX)
+ *
+ * Array conventions (all caller-owned, never retained past the call):
+ *   x   [batch][nx]      state, reference layout include/vi_ekf.h:87-95
+ *   P   [batch][n][n]    covariance, column-major per filter like Eigen's dxMatrix
+ *   u   [batch][6]       raw IMU sample (acc, gyro) -- rotated by q_b_u inside, as vi_ekf.cpp:265-267
+ *   dt  [batch]          propagation interval per filter (t - t_[i_], vi_ekf.cpp:281)
+ *   z   [batch][M][2]    pixel measurements;  slot [batch][M] local feature index (-1 = none)
+ *   result [batch][M]    viekf_meas_result per measurement (-1 for an empty slot)
+ * `where` says whether the pointers of that call are host or device memory
+ * (device pointers must belong to the batch's device).  Calls on one batch must
+ * be serialised by the caller (same contract as VIEKF_ROS::ekf_mtx_, reference
+ * include/vi_ekf_ros.h:65); different batches are independent.
+ *
+ * Every function returns 0 (VIEKF_OK) or a negative viekf_status; nothing
+ * throws or exits across this boundary (the reference's NAN_CHECK -> exit(0),
+ * include/vi_ekf.h:29-37, becomes the per-filter status word).
+ * There is NO CPU fallback: without a usable HIP device the calls fail with
+ * VIEKF_ERR_NO_DEVICE.
+ */
+#ifndef VIEKF_H
+#define VIEKF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIEKF_ABI_VERSION 1
+
+typedef enum viekf_status {
+  VIEKF_OK = 0,
+  VIEKF_ERR_INVALID = -1,   /* bad argument (null pointer, size, slot out of range ...) */
+  VIEKF_ERR_NO_DEVICE = -2, /* no HIP device / device index out of range */
+  VIEKF_ERR_HIP = -3,       /* a HIP runtime call failed; see viekf_last_error() */
+  VIEKF_ERR_YAML = -4,      /* parameter file missing / key missing / wrong length */
+  VIEKF_ERR_UNSUPPORTED = -5
+} viekf_status;
+
+typedef enum viekf_mem { VIEKF_HOST = 0, VIEKF_DEVICE = 1 } viekf_mem;
+
+/* reference include/vi_ekf.h:132-138 (same numeric values) */
+typedef enum viekf_meas_result {
+  VIEKF_MEAS_SKIPPED = -1, /* slot < 0: nothing to do (ragged batches) */
+  VIEKF_MEAS_SUCCESS = 0,
+  VIEKF_MEAS_GATED = 1,
+  VIEKF_MEAS_NAN = 2,
+  VIEKF_MEAS_INVALID = 3,
+  VIEKF_MEAS_NEW_FEATURE = 4
+} viekf_meas_result;
+
+/* reference include/vi_ekf.h:113-124 (same numeric values) */
+typedef enum viekf_meas_type {
+  VIEKF_ACC = 0, VIEKF_ALT, VIEKF_ATT, VIEKF_POS, VIEKF_VEL, VIEKF_QZETA, VIEKF_FEAT, VIEKF_PIXEL_VEL,
+  VIEKF_DEPTH, VIEKF_INV_DEPTH, VIEKF_TOTAL_MEAS
+} viekf_meas_type;
+
+/* per-filter status bits, mirroring the predicates of reference src/vi_ekf/vi_ekf_error.cpp:6-38 */
+#define VIEKF_FLAG_NAN 1u            /* NaNsInTheHouse */
+#define VIEKF_FLAG_BLOWING_UP 2u     /* BlowingUp (> 1e6) */
+#define VIEKF_FLAG_NEGATIVE_DEPTH 4u /* NegativeDepth (seen before fix_depth repaired it) */
+
+/* The keys VIEKF::load reads (reference src/vi_ekf/vi_ekf.cpp:114-131, params/ekf.yaml). */
+typedef struct viekf_params {
+  double x0[17];
+  double P0[16];
+  double Qx[16];
+  double lambda[16];
+  double Qu[6];          /* diagonal (get_yaml_diag) */
+  double P0_feat[3];     /* diagonal */
+  double Qx_feat[3];     /* diagonal */
+  double lambda_feat[3];
+  double cam_center[2];
+  double focal_len[2];
+  double q_b_c[4];
+  double p_b_c[3];
+  double q_b_u[4];
+  double min_depth;
+  double keyframe_overlap_threshold;
+  int32_t use_drag_term;
+  int32_t use_partial_update;
+  int32_t use_keyframe_reset;
+  char name[64];
+} viekf_params;
+
+typedef struct viekf_batch viekf_batch;
+
+/* library */
+int viekf_abi_version(void);
+const char *viekf_last_error(void);       /* thread-local message of the last failing call */
+int viekf_device_count(int32_t *count);   /* VIEKF_OK with *count==0 when no GPU is present */
+
+/* parameters.  Replaces VIEKF::load's YAML reading, src/vi_ekf/vi_ekf.cpp:101-131 */
+int viekf_params_default(viekf_params *p); /* zeros, identity quaternions, flags as params/ekf.yaml */
+int viekf_params_load_yaml(const char *path, viekf_params *p);
+
+/* construction.  Replaces VIEKF::VIEKF / init() / init(...) / the populate part of load(),
+ * src/vi_ekf/vi_ekf.cpp:7-99,134-150: every filter starts at x0, diag(P0 | P0_feat...), no features. */
+int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params *p, int32_t device,
+                       viekf_batch **out);
+int viekf_batch_destroy(viekf_batch *b);
+int viekf_batch_reset(viekf_batch *b);    /* back to the state viekf_batch_create left */
+int viekf_batch_dims(const viekf_batch *b, int32_t *batch, int32_t *num_features, int32_t *nx, int32_t *n);
+/* run all later calls of this batch on an existing hipStream_t (e.g. torch's current stream); NULL = own stream */
+int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
+int viekf_batch_sync(viekf_batch *b);
+/* kernel family: 0 = auto, 1 = streaming (P in HBM/L2, any num_features), 2 = resident (P on chip) */
+int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
+
+/* state access.  Replaces get_state()/get_covariance()/get_len_features(), include/vi_ekf.h:271-286,
+ * and set_x0 / set_imu_bias, src/vi_ekf/vi_ekf.cpp:157-184.  Any pointer may be NULL (skipped). */
+int viekf_batch_get_state(viekf_batch *b, double *x, double *P, int32_t *len_features, viekf_mem where);
+int viekf_batch_set_state(viekf_batch *b, const double *x, const double *P, const int32_t *len_features,
+                          viekf_mem where);
+int viekf_batch_get_status(viekf_batch *b, uint32_t *flags /*[batch]*/, viekf_mem where);
+
+/* numeric core of VIEKF::propagate_state, src/vi_ekf/vi_ekf.cpp:262-318
+ * (dynamics vi_ekf_dyn.cpp:14-135, boxplus vi_ekf_helper.cpp:88-98, fix_depth :128-156). */
+int viekf_batch_propagate(viekf_batch *b, const double *u, const double *dt, viekf_mem where);
+
+/* VIEKF::init_feature, src/vi_ekf/vi_ekf_feat.cpp:6-47, for the filters with mask[i] != 0
+ * (mask NULL = all).  depth NaN -> 2*min_depth.  ok[i] = 1 if a slot was taken (may be NULL). */
+int viekf_batch_init_feature(viekf_batch *b, const double *pix /*[batch][2]*/, const double *depth /*[batch]*/,
+                             const uint8_t *mask, int32_t *ok, viekf_mem where);
+
+/* M sequential ACTIVE FEAT updates per filter: VIEKF::update + h_feat,
+ * src/vi_ekf/vi_ekf_meas.cpp:196-278,354-367, applied in array order m = 0..M-1
+ * (the caller supplies the reference's reverse in-frame order, vi_ekf_meas.cpp:150-176).
+ * R: 2x2 column-major; r_mode 0 = one R for all, 1 = R[batch][4], 2 = R[batch][M][4]. */
+int viekf_batch_update_feat(viekf_batch *b, const double *z, const int32_t *slot, int32_t M, const double *R,
+                            int32_t r_mode, int32_t *result, viekf_mem where);
+
+/* one hot-path step = propagate + M feature updates, fused where the kernel family allows */
+int viekf_batch_step(viekf_batch *b, const double *u, const double *dt, const double *z, const int32_t *slot,
+                     int32_t M, const double *R, int32_t r_mode, int32_t *result, viekf_mem where);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIEKF_H */

@@ -1,0 +1,485 @@
+// viekf_capi.hip -- implementation of the C ABI declared in include/viekf.h (libviekf_hip.so).
+// Host side of the MI355X-native batched VI-EKF core: owns the device buffers, stages
+// host-pointer arguments, launches the gfx950 kernels.  No CPU fallback exists on purpose.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/viekf.h"
+#include "viekf_host.hpp"
+#include "viekf_kernels_stream.hpp"
+
+using namespace viekf;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(VIEKF_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e_));            \
+  } while (0)
+
+constexpr int kThreads = 256;
+
+}  // namespace
+
+struct viekf_batch {
+  int B = 0, N = 0, nx = 0, nxs = 0, n = 0, ld = 0, device = 0;
+  viekf_params params;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *d_x = nullptr, *d_P = nullptr, *d_Qx = nullptr, *d_lambda = nullptr, *d_ws = nullptr, *d_x0 = nullptr,
+         *d_Pdiag = nullptr;
+  int* d_len = nullptr;
+  unsigned* d_flags = nullptr;
+  long ws_stride = 0;
+  char* d_stage = nullptr;
+  size_t stage_bytes = 0, stage_used = 0;
+  int family = 0;
+  DevParams dp;
+};
+
+namespace {
+
+StreamArgs make_args(const viekf_batch* b) {
+  StreamArgs a;
+  a.x = b->d_x; a.P = b->d_P; a.len = b->d_len; a.flags = b->d_flags;
+  a.Qx = b->d_Qx; a.lambda = b->d_lambda; a.ws = b->d_ws;
+  a.B = b->B; a.N = b->N; a.nx = b->nx; a.nxs = b->nxs; a.n = b->n; a.ld = b->ld;
+  a.ws_stride = b->ws_stride;
+  a.p = b->dp;
+  return a;
+}
+
+// bump allocator over one device staging region (host-pointer calls only)
+int stage_begin(viekf_batch* b, size_t need) {
+  need += 4096;
+  if (need > b->stage_bytes) {
+    if (b->d_stage) {
+      HIP_TRY(hipStreamSynchronize(b->stream));
+      HIP_TRY(hipFree(b->d_stage));
+      b->d_stage = nullptr;
+      b->stage_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&b->d_stage, need));
+    b->stage_bytes = need;
+  }
+  b->stage_used = 0;
+  return VIEKF_OK;
+}
+
+void* stage_take(viekf_batch* b, size_t bytes) {
+  const size_t off = (b->stage_used + 255) & ~size_t(255);
+  b->stage_used = off + bytes;
+  return b->d_stage + off;
+}
+
+// returns a device pointer for an input array: the pointer itself (device) or a staged copy (host)
+template <typename Tp>
+int in_ptr(viekf_batch* b, const Tp* src, size_t count, viekf_mem where, const Tp** out) {
+  if (!src) { *out = nullptr; return VIEKF_OK; }
+  if (where == VIEKF_DEVICE) { *out = src; return VIEKF_OK; }
+  Tp* d = static_cast<Tp*>(stage_take(b, count * sizeof(Tp)));
+  HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(Tp), hipMemcpyHostToDevice, b->stream));
+  *out = d;
+  return VIEKF_OK;
+}
+
+size_t stage_size(size_t bytes) { return bytes + 256; }
+
+int check_batch(const viekf_batch* b) {
+  if (!b) return fail(VIEKF_ERR_INVALID, "null batch handle");
+  return VIEKF_OK;
+}
+
+size_t lds_propagate(const viekf_batch* b) {
+  return sizeof(double) * (size_t)(b->nxs + 256 + 96 + 256 + 256 + 96 + 256 + 256 + 16) + sizeof(BodyCtx) + 16;
+}
+size_t lds_update(const viekf_batch* b) { return sizeof(double) * (size_t)(b->nxs + 5 * b->n + 32); }
+
+int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_propagate_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
+                     d_dt);
+  HIP_TRY(hipGetLastError());
+  return VIEKF_OK;
+}
+
+int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, const double* d_R, int r_mode,
+                  int* d_res) {
+  StreamArgs a = make_args(b);
+  long rsb = 0, rsm = 0;
+  if (r_mode == 1) rsb = 4;
+  else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
+  hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
+                     d_slot, M, d_R, rsb, rsm, d_res);
+  HIP_TRY(hipGetLastError());
+  return VIEKF_OK;
+}
+
+size_t r_count(const viekf_batch* b, int M, int r_mode) {
+  return r_mode == 0 ? 4 : (r_mode == 1 ? 4 * (size_t)b->B : 4 * (size_t)b->B * M);
+}
+
+}  // namespace
+
+extern "C" {
+
+int viekf_abi_version(void) { return VIEKF_ABI_VERSION; }
+
+const char* viekf_last_error(void) { return g_last_error.c_str(); }
+
+int viekf_device_count(int32_t* count) {
+  if (!count) return fail(VIEKF_ERR_INVALID, "count is null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  *count = c;
+  return VIEKF_OK;
+}
+
+int viekf_params_default(viekf_params* p) {
+  if (!p) return fail(VIEKF_ERR_INVALID, "params is null");
+  std::memset(p, 0, sizeof(*p));
+  p->x0[6] = 1.0;
+  p->q_b_c[0] = 1.0;
+  p->q_b_u[0] = 1.0;
+  p->focal_len[0] = p->focal_len[1] = 1.0;
+  for (int i = 0; i < 16; i++) p->lambda[i] = 1.0;
+  for (int i = 0; i < 3; i++) p->lambda_feat[i] = 1.0;
+  p->min_depth = 1.5;
+  p->keyframe_overlap_threshold = 0.8;
+  p->use_drag_term = 1;
+  p->use_partial_update = 1;
+  p->use_keyframe_reset = 1;
+  std::snprintf(p->name, sizeof p->name, "ekf");
+  return VIEKF_OK;
+}
+
+// VIEKF::load, reference src/vi_ekf/vi_ekf.cpp:101-131 (same keys, same required lengths)
+int viekf_params_load_yaml(const char* path, viekf_params* p) {
+  if (!path || !p) return fail(VIEKF_ERR_INVALID, "null argument");
+  viekf_params_default(p);
+  YamlMap m;
+  std::string err, name;
+  if (!yaml_parse_file(path, m, err)) return fail(VIEKF_ERR_YAML, err);
+  double v = 0.0;
+#define GET(key, dst, cnt) \
+  if (!yaml_get_doubles(m, key, dst, cnt, err)) return fail(VIEKF_ERR_YAML, std::string(path) + ": " + err)
+  if (!yaml_get_string(m, "name", name, err)) return fail(VIEKF_ERR_YAML, std::string(path) + ": " + err);
+  std::snprintf(p->name, sizeof p->name, "%s", name.c_str());
+  GET("min_depth", &p->min_depth, 1);
+  GET("keyframe_overlap_threshold", &p->keyframe_overlap_threshold, 1);
+  GET("use_drag_term", &v, 1); p->use_drag_term = v != 0.0;
+  GET("use_partial_update", &v, 1); p->use_partial_update = v != 0.0;
+  GET("use_keyframe_reset", &v, 1); p->use_keyframe_reset = v != 0.0;
+  GET("x0", p->x0, 17);
+  GET("P0", p->P0, 16);
+  GET("Qx", p->Qx, 16);
+  GET("Qu", p->Qu, 6);
+  GET("lambda", p->lambda, 16);
+  GET("P0_feat", p->P0_feat, 3);
+  GET("Qx_feat", p->Qx_feat, 3);
+  GET("lambda_feat", p->lambda_feat, 3);
+  GET("cam_center", p->cam_center, 2);
+  GET("focal_len", p->focal_len, 2);
+  GET("q_b_c", p->q_b_c, 4);
+  GET("p_b_c", p->p_b_c, 3);
+  GET("q_b_u", p->q_b_u, 4);
+#undef GET
+  return VIEKF_OK;
+}
+
+int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* p, int32_t device,
+                       viekf_batch** out) {
+  if (!p || !out) return fail(VIEKF_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (batch <= 0 || num_features < 0 || num_features > 4096)
+    return fail(VIEKF_ERR_INVALID, "batch must be > 0 and 0 <= num_features <= 4096");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    return fail(VIEKF_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  }
+  if (device < 0 || device >= ndev) return fail(VIEKF_ERR_NO_DEVICE, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  viekf_batch* b = new viekf_batch();
+  b->B = batch; b->N = num_features; b->device = device;
+  b->nx = 17 + 5 * num_features;
+  b->n = 16 + 3 * num_features;
+  b->nxs = (b->nx + 1) & ~1;
+  b->ld = (b->n + 1) & ~1;
+  b->params = *p;
+  DevParams& d = b->dp;
+  std::memcpy(d.Qu, p->Qu, sizeof d.Qu);
+  std::memcpy(d.P0_feat, p->P0_feat, sizeof d.P0_feat);
+  std::memcpy(d.cam_center, p->cam_center, sizeof d.cam_center);
+  std::memcpy(d.focal, p->focal_len, sizeof d.focal);
+  std::memcpy(d.q_b_c, p->q_b_c, sizeof d.q_b_c);
+  std::memcpy(d.p_b_c, p->p_b_c, sizeof d.p_b_c);
+  std::memcpy(d.q_b_u, p->q_b_u, sizeof d.q_b_u);
+  d.min_depth = p->min_depth;
+  d.use_drag_term = p->use_drag_term;
+  d.use_partial_update = p->use_partial_update;
+  const WsLayout L(b->N, b->n);
+  b->ws_stride = L.total;
+#define ALLOC(ptr, bytes)                                                        \
+  do {                                                                           \
+    hipError_t e_ = hipMalloc(&(ptr), (bytes));                                  \
+    if (e_ != hipSuccess) {                                                      \
+      viekf_batch_destroy(b);                                                    \
+      return fail(VIEKF_ERR_HIP, std::string("hipMalloc failed: ") + hipGetErrorString(e_)); \
+    }                                                                            \
+  } while (0)
+  ALLOC(b->d_x, sizeof(double) * (size_t)batch * b->nxs);
+  ALLOC(b->d_P, sizeof(double) * (size_t)batch * b->n * b->ld);
+  ALLOC(b->d_Qx, sizeof(double) * (size_t)b->n);
+  ALLOC(b->d_lambda, sizeof(double) * (size_t)b->n);
+  ALLOC(b->d_Pdiag, sizeof(double) * (size_t)b->n);
+  ALLOC(b->d_x0, sizeof(double) * 17);
+  ALLOC(b->d_ws, sizeof(double) * (size_t)batch * b->ws_stride);
+  ALLOC(b->d_len, sizeof(int) * (size_t)batch);
+  ALLOC(b->d_flags, sizeof(unsigned) * (size_t)batch);
+#undef ALLOC
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    viekf_batch_destroy(b);
+    return fail(VIEKF_ERR_HIP, std::string("hipStreamCreate failed: ") + hipGetErrorString(e));
+  }
+  b->own_stream = true;
+  // shared per-batch vectors: Qx diag, lambda, initial P diagonal (vi_ekf.cpp:134-146)
+  std::vector<double> Qx(b->n), lam(b->n), Pd(b->n);
+  for (int i = 0; i < 16; i++) { Qx[i] = p->Qx[i]; lam[i] = p->lambda[i]; Pd[i] = p->P0[i]; }
+  for (int i = 0; i < b->N; i++)
+    for (int k = 0; k < 3; k++) {
+      Qx[16 + 3 * i + k] = p->Qx_feat[k];
+      lam[16 + 3 * i + k] = p->lambda_feat[k];
+      Pd[16 + 3 * i + k] = p->P0_feat[k];
+    }
+  int rc = VIEKF_OK;
+  auto up = [&](double* dptr, const double* h, size_t cnt) {
+    if (hipMemcpy(dptr, h, cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = VIEKF_ERR_HIP;
+  };
+  up(b->d_Qx, Qx.data(), b->n);
+  up(b->d_lambda, lam.data(), b->n);
+  up(b->d_Pdiag, Pd.data(), b->n);
+  up(b->d_x0, p->x0, 17);
+  if (rc == VIEKF_OK) rc = viekf_batch_reset(b);
+  if (rc != VIEKF_OK) {
+    viekf_batch_destroy(b);
+    return rc == VIEKF_ERR_HIP ? fail(rc, "parameter upload failed") : rc;
+  }
+  *out = b;
+  return VIEKF_OK;
+}
+
+int viekf_batch_destroy(viekf_batch* b) {
+  if (!b) return VIEKF_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return VIEKF_OK;
+}
+
+int viekf_batch_reset(viekf_batch* b) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_reset, dim3(b->B), dim3(256), 0, b->stream, a, b->d_x0, b->d_Pdiag);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_dims(const viekf_batch* b, int32_t* batch, int32_t* num_features, int32_t* nx, int32_t* n) {
+  if (int rc = check_batch(b)) return rc;
+  if (batch) *batch = b->B;
+  if (num_features) *num_features = b->N;
+  if (nx) *nx = b->nx;
+  if (n) *n = b->n;
+  return VIEKF_OK;
+}
+
+int viekf_batch_set_stream(viekf_batch* b, void* hip_stream) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->own_stream && b->stream) { HIP_TRY(hipStreamDestroy(b->stream)); b->stream = nullptr; b->own_stream = false; }
+  if (hip_stream) {
+    b->stream = static_cast<hipStream_t>(hip_stream);
+    b->own_stream = false;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = true;
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_sync(viekf_batch* b) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_set_kernel(viekf_batch* b, int32_t family) {
+  if (int rc = check_batch(b)) return rc;
+  if (family < 0 || family > 2) return fail(VIEKF_ERR_INVALID, "kernel family must be 0, 1 or 2");
+  if (family == 2) return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family not available in this build");
+  b->family = family;
+  return VIEKF_OK;
+}
+
+int viekf_batch_get_state(viekf_batch* b, double* x, double* P, int32_t* len_features, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  const hipMemcpyKind kind = where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (x)
+    HIP_TRY(hipMemcpy2DAsync(x, sizeof(double) * b->nx, b->d_x, sizeof(double) * b->nxs, sizeof(double) * b->nx, b->B,
+                             kind, b->stream));
+  if (P)
+    HIP_TRY(hipMemcpy2DAsync(P, sizeof(double) * b->n, b->d_P, sizeof(double) * b->ld, sizeof(double) * b->n,
+                             (size_t)b->B * b->n, kind, b->stream));
+  if (len_features) HIP_TRY(hipMemcpyAsync(len_features, b->d_len, sizeof(int32_t) * b->B, kind, b->stream));
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, const int32_t* len_features,
+                          viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  const hipMemcpyKind kind = where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (len_features && where == VIEKF_HOST)
+    for (int i = 0; i < b->B; i++)
+      if (len_features[i] < 0 || len_features[i] > b->N)
+        return fail(VIEKF_ERR_INVALID, "len_features out of range");
+  if (x)
+    HIP_TRY(hipMemcpy2DAsync(b->d_x, sizeof(double) * b->nxs, x, sizeof(double) * b->nx, sizeof(double) * b->nx, b->B,
+                             kind, b->stream));
+  if (P)
+    HIP_TRY(hipMemcpy2DAsync(b->d_P, sizeof(double) * b->ld, P, sizeof(double) * b->n, sizeof(double) * b->n,
+                             (size_t)b->B * b->n, kind, b->stream));
+  if (len_features) HIP_TRY(hipMemcpyAsync(b->d_len, len_features, sizeof(int32_t) * b->B, kind, b->stream));
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_get_status(viekf_batch* b, uint32_t* flags, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!flags) return fail(VIEKF_ERR_INVALID, "flags is null");
+  HIP_TRY(hipSetDevice(b->device));
+  const hipMemcpyKind kind = where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIP_TRY(hipMemcpyAsync(flags, b->d_flags, sizeof(uint32_t) * b->B, kind, b->stream));
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || !dt) return fail(VIEKF_ERR_INVALID, "u and dt must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const double *d_u = nullptr, *d_dt = nullptr;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B))) return rc;
+  if (int rc = in_ptr(b, u, (size_t)6 * b->B, where, &d_u)) return rc;
+  if (int rc = in_ptr(b, dt, (size_t)b->B, where, &d_dt)) return rc;
+  if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_init_feature(viekf_batch* b, const double* pix, const double* depth, const uint8_t* mask, int32_t* ok,
+                             viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!pix) return fail(VIEKF_ERR_INVALID, "pix must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const double *d_pix = nullptr, *d_depth = nullptr;
+  const uint8_t* d_mask = nullptr;
+  int* d_ok = nullptr;
+  if (where == VIEKF_HOST) {
+    if (int rc = stage_begin(b, stage_size(sizeof(double) * 2 * b->B) + stage_size(sizeof(double) * b->B) +
+                                    stage_size(b->B) + stage_size(sizeof(int) * b->B)))
+      return rc;
+  }
+  if (int rc = in_ptr(b, pix, (size_t)2 * b->B, where, &d_pix)) return rc;
+  if (int rc = in_ptr(b, depth, (size_t)b->B, where, &d_depth)) return rc;
+  if (int rc = in_ptr(b, mask, (size_t)b->B, where, &d_mask)) return rc;
+  if (ok) d_ok = where == VIEKF_DEVICE ? ok : static_cast<int*>(stage_take(b, sizeof(int) * b->B));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_init_feature<kThreads>, dim3(b->B), dim3(kThreads), 0, b->stream, a, d_pix, d_depth, d_mask,
+                     d_ok);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (ok) HIP_TRY(hipMemcpyAsync(ok, d_ok, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+static int update_or_step(viekf_batch* b, const double* u, const double* dt, bool with_propagate, const double* z,
+                          const int32_t* slot, int32_t M, const double* R, int32_t r_mode, int32_t* result,
+                          viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (M < 0) return fail(VIEKF_ERR_INVALID, "M must be >= 0");
+  if (r_mode < 0 || r_mode > 2) return fail(VIEKF_ERR_INVALID, "r_mode must be 0, 1 or 2");
+  if (M > 0 && (!z || !slot || !R)) return fail(VIEKF_ERR_INVALID, "z, slot and R must not be null when M > 0");
+  if (with_propagate && (!u || !dt)) return fail(VIEKF_ERR_INVALID, "u and dt must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t BM = (size_t)b->B * (size_t)M;
+  const double *d_u = nullptr, *d_dt = nullptr, *d_z = nullptr, *d_R = nullptr;
+  const int32_t* d_slot = nullptr;
+  int32_t* d_res = nullptr;
+  if (where == VIEKF_HOST) {
+    size_t need = stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B) +
+                  stage_size(sizeof(double) * 2 * BM) + stage_size(sizeof(int32_t) * BM) * 2 +
+                  stage_size(sizeof(double) * r_count(b, M, r_mode));
+    if (int rc = stage_begin(b, need)) return rc;
+  }
+  if (with_propagate) {
+    if (int rc = in_ptr(b, u, (size_t)6 * b->B, where, &d_u)) return rc;
+    if (int rc = in_ptr(b, dt, (size_t)b->B, where, &d_dt)) return rc;
+  }
+  if (M > 0) {
+    if (int rc = in_ptr(b, z, 2 * BM, where, &d_z)) return rc;
+    if (int rc = in_ptr(b, slot, BM, where, &d_slot)) return rc;
+    if (int rc = in_ptr(b, R, r_count(b, M, r_mode), where, &d_R)) return rc;
+    if (result) d_res = where == VIEKF_DEVICE ? result : static_cast<int32_t*>(stage_take(b, sizeof(int32_t) * BM));
+  }
+  if (with_propagate)
+    if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+  if (M > 0)
+    if (int rc = launch_update(b, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
+  if (where == VIEKF_HOST) {
+    if (result && M > 0) HIP_TRY(hipMemcpyAsync(result, d_res, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot, int32_t M, const double* R,
+                            int32_t r_mode, int32_t* result, viekf_mem where) {
+  return update_or_step(b, nullptr, nullptr, false, z, slot, M, R, r_mode, result, where);
+}
+
+int viekf_batch_step(viekf_batch* b, const double* u, const double* dt, const double* z, const int32_t* slot,
+                     int32_t M, const double* R, int32_t r_mode, int32_t* result, viekf_mem where) {
+  return update_or_step(b, u, dt, true, z, slot, M, R, r_mode, result, where);
+}
+
+}  // extern "C"

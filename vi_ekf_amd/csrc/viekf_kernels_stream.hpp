@@ -1,0 +1,472 @@
+// viekf_kernels_stream.hpp -- "streaming" kernel family: one workgroup per filter, covariance stays
+// in HBM/L2 (column-major, leading dimension ld) and is updated in place.  Works for any number of
+// features; it is the path for wide P (N=150) and the correctness baseline for the resident family.
+//
+// Structure exploited (exact in real arithmetic):
+//   A = [[A_bb, 0], [A_fb, blockdiag(A_ff)]]   (vi_ekf_dyn.cpp:55-71,121-128: body rows never depend on features)
+//   => Phi = I + A dt + A^2 dt^2/2 has the same shape, so  P+ = Phi P Phi^T + Gd Qu Gd^T + Qx  (vi_ekf.cpp:302-304)
+//      needs per 3x3 block only its own block plus the 16 body rows/columns.
+//   H of a FEAT measurement has one 2x2 block (vi_ekf_meas.cpp:366) => W = P H^T is two columns of P and
+//      (I-KH)P(I-KH)^T + KRK^T - P = -K W^T, so the partial update (vi_ekf_meas.cpp:254-257) is
+//      P_ij -= Lambda_ij (K_i . W_j),  Lambda_ij = l_i + l_j - l_i l_j  (vi_ekf.cpp:83,146).
+#pragma once
+#include "viekf_device.hpp"
+
+namespace viekf {
+
+struct StreamArgs {
+  double* x;            // [B][nxs]
+  double* P;            // [B][n][ld]
+  int* len;             // [B]
+  unsigned* flags;      // [B]
+  const double* Qx;     // [n] diagonal
+  const double* lambda; // [n]
+  double* ws;           // [B][ws_stride]
+  int B, N, nx, nxs, n, ld;
+  long ws_stride;
+  DevParams p;
+};
+
+// workspace carve-up (doubles) for one filter
+struct WsLayout {
+  long phi_fb, phi_ff, gd, U, Ut, pbr, pbc, total;
+  __host__ __device__ WsLayout(int N, int n) {
+    long o = 0;
+    phi_fb = o; o += 3L * N * 16;   // [3N][16]
+    phi_ff = o; o += 9L * N;        // [N][9]
+    gd = o;     o += 6L * n;        // [n][6]
+    U = o;      o += 3L * N * 16;   // [3N][16]   (Phi P)[feat rows, body cols]
+    Ut = o;     o += 16L * 3 * N;   // [16][3N]   (P Phi^T)[body rows, feat cols]
+    pbr = o;    o += 16L * n;       // [16][n]    copy of P[body rows, :]
+    pbc = o;    o += 16L * n;       // [16][n]    copy of P[:, body cols], stored [k][i]
+    total = (o + 1) & ~1L;
+  }
+};
+
+constexpr unsigned FLAG_NAN = 1u, FLAG_BLOWUP = 2u, FLAG_NEGDEPTH = 4u;
+
+// fix_depth (vi_ekf_helper.cpp:128-156) for feature i of the block's filter; xs is the LDS copy of x
+__device__ __forceinline__ void fix_depth_one(double* xs, double* P, int ld, int i, const DevParams& p, unsigned& flag) {
+  const int xR = xZ + 5 * i + 4, dR = dxZ + 3 * i + 2;
+  double rho = xs[xR];
+  const double reset = 1.0 / (2.0 * p.min_depth);
+  if (rho != rho) { rho = reset; flag |= FLAG_NAN; }
+  if (rho < 0.0) {
+    const double err = reset - rho;
+    P[dR + (long)dR * ld] += err * err;
+    rho = reset;
+    flag |= FLAG_NEGDEPTH;
+  } else if (rho > 1e2) {
+    P[dR + (long)dR * ld] = p.P0_feat[2];
+    rho = reset;
+  }
+  xs[xR] = rho;
+}
+
+// ------------------------------------------------------------------------------------------------
+// propagate: numeric core of VIEKF::propagate_state (vi_ekf.cpp:262-318)
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const double* __restrict__ u_all,
+                                                        const double* __restrict__ dt_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, ld = a.ld;
+  double* xs = smem;                    // [nxs]
+  double* Abb = xs + a.nxs;             // 16x16 row-major
+  double* Gb = Abb + 256;               // 16x6
+  double* Phibb = Gb + 96;              // 16x16
+  double* Mbb = Phibb + 256;            // 16x16
+  double* Gdb = Mbb + 256;              // 16x6
+  double* Pbb = Gdb + 96;               // 16x16 row-major copy of P_bb
+  double* T16 = Pbb + 256;              // 16x16 scratch
+  double* xdb = T16 + 256;              // 16
+  BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
+
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const int len = a.len[b];
+  const int nf = 3 * len, nact = 16 + nf;
+  const double dt = dt_all[b];
+  const WsLayout L(a.N, n);
+  double* ws = a.ws + (long)b * a.ws_stride;
+  double* phi_fb = ws + L.phi_fb;
+  double* phi_ff = ws + L.phi_ff;
+  double* gd = ws + L.gd;
+  double* U = ws + L.U;
+  double* Ut = ws + L.Ut;
+  double* pbr = ws + L.pbr;
+  double* pbc = ws + L.pbc;
+
+  for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
+  __syncthreads();
+
+  if (tid == 0) {
+    double ub[6];
+    q_rota(a.p.q_b_u, u_all + (long)b * 6, ub);          // vi_ekf.cpp:265-267
+    q_rota(a.p.q_b_u, u_all + (long)b * 6 + 3, ub + 3);
+    body_ctx(xs, ub, a.p, *ctx);
+    body_dynamics(*ctx, a.p, xdb, Abb, Gb);               // vi_ekf_dyn.cpp:42-80
+  }
+  __syncthreads();
+
+  // ---- body transition blocks (vi_ekf.cpp:302-303 restricted to the 16x16 block)
+  for (int e = tid; e < 256; e += T) {
+    const int r = e >> 4, c = e & 15;
+    double a2 = 0.0;
+    for (int k = 0; k < 16; k++) a2 += Abb[r * 16 + k] * Abb[k * 16 + c];
+    const double id = (r == c) ? 1.0 : 0.0, av = Abb[e];
+    Mbb[e] = id + av * dt / 2.0 + a2 * dt * dt / 6.0;
+    Phibb[e] = id + av * dt + a2 * dt * dt / 2.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < 96; e += T) {
+    const int r = e / 6, k = e % 6;
+    double s = 0.0;
+    for (int c = 0; c < 16; c++) s += Mbb[r * 16 + c] * Gb[c * 6 + k];
+    s *= dt;
+    Gdb[e] = s;
+    gd[r * 6 + k] = s;
+  }
+
+  // ---- per feature: dynamics, Phi_fb / Phi_ff / Gd_f, state step
+  for (int i = tid; i < len; i += T) {
+    double xd3[3], Afv[9], Afg[9], Aff[9];
+    const double* qz = xs + xZ + 5 * i;
+    const double rho = qz[4];
+    feature_dynamics(qz, rho, *ctx, xd3, Afv, Afg, Aff);   // vi_ekf_dyn.cpp:96-134
+    double Aff2[9];
+    mm<3, 3, 3>(Aff, Aff, Aff2);
+    double Mff[9];
+    for (int e = 0; e < 9; e++) {
+      const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+      Mff[e] = id + Aff[e] * dt / 2.0 + Aff2[e] * dt * dt / 6.0;
+      phi_ff[9 * i + e] = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
+    }
+    double gacc[18];
+    for (int e = 0; e < 18; e++) gacc[e] = 0.0;
+    for (int c = 0; c < 16; c++) {
+      for (int r = 0; r < 3; r++) {
+        // A_fb(r,c): non-zero only in the VEL and B_G columns
+        double afb = 0.0;
+        if (c >= dxVEL && c < dxVEL + 3) afb = Afv[r * 3 + (c - dxVEL)];
+        else if (c >= dxB_G && c < dxB_G + 3) afb = Afg[r * 3 + (c - dxB_G)];
+        // (A^2)_fb = A_fb A_bb + A_ff A_fb
+        double a2 = 0.0;
+        for (int k = 0; k < 3; k++) a2 += Afv[r * 3 + k] * Abb[(dxVEL + k) * 16 + c] + Afg[r * 3 + k] * Abb[(dxB_G + k) * 16 + c];
+        if (c >= dxVEL && c < dxVEL + 3)
+          for (int k = 0; k < 3; k++) a2 += Aff[r * 3 + k] * Afv[k * 3 + (c - dxVEL)];
+        else if (c >= dxB_G && c < dxB_G + 3)
+          for (int k = 0; k < 3; k++) a2 += Aff[r * 3 + k] * Afg[k * 3 + (c - dxB_G)];
+        phi_fb[(3 * i + r) * 16 + c] = afb * dt + a2 * dt * dt / 2.0;
+        const double mfb = afb * dt / 2.0 + a2 * dt * dt / 6.0;
+        for (int k = 0; k < 6; k++) gacc[r * 6 + k] += mfb * Gb[c * 6 + k];
+      }
+    }
+    for (int r = 0; r < 3; r++)
+      for (int k = 0; k < 3; k++) {   // G_f = [0 | Afg]  (vi_ekf_dyn.cpp:131-132)
+        double s = 0.0;
+        for (int m = 0; m < 3; m++) s += Mff[r * 3 + m] * Afg[m * 3 + k];
+        gacc[r * 6 + 3 + k] += s;
+      }
+    for (int e = 0; e < 18; e++) gd[(16 + 3 * i) * 6 + e] = gacc[e] * dt;
+    // state step for this feature (boxplus, vi_ekf_helper.cpp:93-97)
+    double qn[4];
+    q_feat_boxplus(qz, xd3[0] * dt, xd3[1] * dt, qn);
+    xs[xZ + 5 * i + 0] = qn[0]; xs[xZ + 5 * i + 1] = qn[1]; xs[xZ + 5 * i + 2] = qn[2]; xs[xZ + 5 * i + 3] = qn[3];
+    xs[xZ + 5 * i + 4] = rho + xd3[2] * dt;
+  }
+  // ---- save the body rows / columns of P before anything is overwritten
+  for (int e = tid; e < 16 * nact; e += T) {
+    const int k = e / nact, j = e % nact;
+    pbr[k * n + j] = P[k + (long)j * ld];
+    pbc[k * n + j] = P[j + (long)k * ld];
+  }
+  for (int e = tid; e < 256; e += T) Pbb[e] = P[(e >> 4) + (long)(e & 15) * ld];
+  __syncthreads();
+  if (tid == 0) {  // body state step (after every feature thread has read the old body state through ctx)
+    double dxb[16], xo[17];
+    for (int i = 0; i < 16; i++) dxb[i] = xdb[i] * dt;
+    body_boxplus(xs, dxb, xo);
+    for (int i = 0; i < 17; i++) xs[i] = xo[i];
+  }
+
+  // ---- U = (Phi P)[feat, body],  Ut = (P Phi^T)[body, feat],  T16 = Phi_bb P_bb
+  for (int e = tid; e < nf * 16; e += T) {
+    const int r = e >> 4, k = e & 15, I = r / 3, rr = r - 3 * I;
+    double s = 0.0, st = 0.0;
+    for (int c = 0; c < 16; c++) {
+      const double ph = phi_fb[r * 16 + c];
+      s += ph * Pbb[c * 16 + k];
+      st += Pbb[k * 16 + c] * ph;
+    }
+    for (int m = 0; m < 3; m++) {
+      const double pf = phi_ff[9 * I + rr * 3 + m];
+      s += pf * pbc[k * n + 16 + 3 * I + m];
+      st += pbr[k * n + 16 + 3 * I + m] * pf;
+    }
+    U[r * 16 + k] = s;
+    Ut[k * nf + r] = st;
+  }
+  for (int e = tid; e < 256; e += T) {
+    const int r = e >> 4, c = e & 15;
+    double s = 0.0;
+    for (int k = 0; k < 16; k++) s += Phibb[r * 16 + k] * Pbb[k * 16 + c];
+    T16[e] = s;
+  }
+  __syncthreads();
+
+  // ---- write P+ : body block
+  for (int e = tid; e < 256; e += T) {
+    const int r = e >> 4, c = e & 15;
+    double s = 0.0;
+    for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
+    double g = 0.0;
+    for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * a.p.Qu[k] * Gdb[c * 6 + k];
+    s = s + g;
+    if (r == c) s += a.Qx[r];
+    P[r + (long)c * ld] = s;
+  }
+  // ---- body/feature cross blocks
+  for (int e = tid; e < nf * 16; e += T) {
+    const int r = e >> 4, k = e & 15;
+    double s = 0.0, st = 0.0;
+    for (int c = 0; c < 16; c++) {
+      s += U[r * 16 + c] * Phibb[k * 16 + c];
+      st += Phibb[k * 16 + c] * Ut[c * nf + r];
+    }
+    double g = 0.0;
+    for (int q = 0; q < 6; q++) g += gd[(16 + r) * 6 + q] * a.p.Qu[q] * Gdb[k * 6 + q];
+    P[(16 + r) + (long)k * ld] = s + g;
+    P[k + (long)(16 + r) * ld] = st + g;
+  }
+  // ---- feature/feature 3x3 blocks, in place (each block needs only itself + saved body strips)
+  for (int e = tid; e < len * len; e += T) {
+    const int I = e % len, J = e / len;
+    const int r0 = 16 + 3 * I, c0 = 16 + 3 * J;
+    double Pij[9], Mij[9], out[9];
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) Pij[r * 3 + c] = P[(r0 + r) + (long)(c0 + c) * ld];
+    for (int r = 0; r < 3; r++)
+      for (int m = 0; m < 3; m++) {
+        double s = 0.0;
+        for (int k = 0; k < 16; k++) s += phi_fb[(3 * I + r) * 16 + k] * pbr[k * n + c0 + m];
+        for (int q = 0; q < 3; q++) s += phi_ff[9 * I + r * 3 + q] * Pij[q * 3 + m];
+        Mij[r * 3 + m] = s;
+      }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double s = 0.0;
+        for (int k = 0; k < 16; k++) s += U[(3 * I + r) * 16 + k] * phi_fb[(3 * J + c) * 16 + k];
+        for (int m = 0; m < 3; m++) s += Mij[r * 3 + m] * phi_ff[9 * J + c * 3 + m];
+        double g = 0.0;
+        for (int q = 0; q < 6; q++) g += gd[(r0 + r) * 6 + q] * a.p.Qu[q] * gd[(c0 + c) * 6 + q];
+        s = s + g;
+        if (I == J && r == c) s += a.Qx[r0 + r];
+        out[r * 3 + c] = s;
+      }
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) P[(r0 + r) + (long)(c0 + c) * ld] = out[r * 3 + c];
+  }
+  // inactive slots: Phi = I and G = 0 there, so only Qx is added (vi_ekf.cpp:139-144,304)
+  for (int d = nact + tid; d < n; d += T) P[d + (long)d * ld] += a.Qx[d];
+  __syncthreads();
+
+  // ---- fix_depth (vi_ekf.cpp:311) and write the state back
+  unsigned flag = 0;
+  for (int i = tid; i < len; i += T) fix_depth_one(xs, P, ld, i, a.p, flag);
+  __syncthreads();
+  for (int i = tid; i < xZ + 5 * len; i += T) {
+    const double v = xs[i];
+    if (v != v) flag |= FLAG_NAN;
+    if (v > 1e6) flag |= FLAG_BLOWUP;
+    xg[i] = v;
+  }
+  if (flag) atomicOr(&a.flags[b], flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// M sequential active FEAT updates: VIEKF::update + h_feat (vi_ekf_meas.cpp:196-278, 354-367)
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const double* __restrict__ z_all,
+                                                          const int* __restrict__ slot_all, int M,
+                                                          const double* __restrict__ R_all, long r_stride_b,
+                                                          long r_stride_m, int* __restrict__ result_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, ld = a.ld;
+  double* xs = smem;           // [nxs]
+  double* W = xs + a.nxs;      // [n][2]
+  double* K = W + 2 * n;       // [n][2]
+  double* lam = K + 2 * n;     // [n]
+  double* sm = lam + n;        // small scratch: zhat(2) Hb(4) res(2) Sinv(4) = 12, dxb(16)
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const int len = a.len[b];
+  const int nact = 16 + 3 * len;
+  unsigned flag = 0;
+
+  for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
+  for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
+  __syncthreads();
+
+  for (int m = 0; m < M; m++) {
+    const int slot = slot_all[(long)b * M + m];
+    int* res = result_all ? &result_all[(long)b * M + m] : nullptr;
+    if (slot < 0) { if (res && tid == 0) *res = -1; continue; }
+    if (slot >= len) { if (res && tid == 0) *res = 3; continue; }  // MEAS_INVALID
+    const double* z = z_all + ((long)b * M + m) * 2;
+    const double* R = R_all + (long)b * r_stride_b + (long)m * r_stride_m;  // column-major 2x2
+    const double z0 = z[0], z1 = z[1];
+    if (z0 != z0 || z1 != z1) { if (res && tid == 0) *res = 2; continue; }  // MEAS_NAN (vi_ekf_meas.cpp:136-137)
+    const int j0 = 16 + 3 * slot;
+    if (tid == 0) {
+      double zhat[2], Hb[4];
+      h_feat(xs + xZ + 5 * slot, a.p, zhat, Hb);
+      sm[0] = zhat[0]; sm[1] = zhat[1];
+      sm[2] = Hb[0]; sm[3] = Hb[1]; sm[4] = Hb[2]; sm[5] = Hb[3];
+      sm[6] = z0 - zhat[0]; sm[7] = z1 - zhat[1];      // residual (vi_ekf_meas.cpp:220)
+    }
+    __syncthreads();
+    const double h00 = sm[2], h01 = sm[3], h10 = sm[4], h11 = sm[5];
+    // W = P H^T : two columns of P (coalesced along i)
+    for (int i = tid; i < nact; i += T) {
+      const double p0 = P[i + (long)j0 * ld], p1 = P[i + (long)(j0 + 1) * ld];
+      W[2 * i + 0] = p0 * h00 + p1 * h01;
+      W[2 * i + 1] = p0 * h10 + p1 * h11;
+    }
+    __syncthreads();
+    // S = H W[j0:j0+2] + R ; every lane computes it (uniform)
+    double S[4], Si[4];
+    {
+      const double w00 = W[2 * j0 + 0], w01 = W[2 * j0 + 1], w10 = W[2 * (j0 + 1) + 0], w11 = W[2 * (j0 + 1) + 1];
+      S[0] = h00 * w00 + h01 * w10 + R[0];
+      S[1] = h00 * w01 + h01 * w11 + R[2];
+      S[2] = h10 * w00 + h11 * w10 + R[1];
+      S[3] = h10 * w01 + h11 * w11 + R[3];
+    }
+    inv2(S, Si);
+    const double r0 = sm[6], r1 = sm[7];
+    const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;  // vi_ekf_meas.cpp:234
+    if (mahal > 9.0) {                                   // gate (:235-239): returns before fix_depth
+      if (res && tid == 0) *res = 1;
+      __syncthreads();
+      continue;
+    }
+    // K = W S^-1 (:241) and NaN guard (:247)
+    int bad = 0;
+    for (int i = tid; i < nact; i += T) {
+      const double w0 = W[2 * i], w1 = W[2 * i + 1];
+      const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
+      K[2 * i] = k0; K[2 * i + 1] = k1;
+      if (k0 != k0 || k1 != k1) bad = 1;
+    }
+    if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
+    bad = __syncthreads_or(bad);
+    if (!bad) {
+      const bool partial = a.p.use_partial_update != 0;
+      // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263)
+      if (tid == 0) {
+        double dxb[16], xo[17];
+        for (int i = 0; i < 16; i++) {
+          const double l = partial ? lam[i] : 1.0;
+          dxb[i] = (l * K[2 * i]) * r0 + (l * K[2 * i + 1]) * r1;
+        }
+        body_boxplus(xs, dxb, xo);
+        for (int i = 0; i < 17; i++) xs[i] = xo[i];
+      }
+      for (int f = tid; f < len; f += T) {
+        const int d = 16 + 3 * f;
+        double dv[3];
+        for (int q = 0; q < 3; q++) {
+          const double l = partial ? lam[d + q] : 1.0;
+          dv[q] = (l * K[2 * (d + q)]) * r0 + (l * K[2 * (d + q) + 1]) * r1;
+        }
+        double qn[4];
+        q_feat_boxplus(xs + xZ + 5 * f, dv[0], dv[1], qn);
+        double* xf = xs + xZ + 5 * f;
+        xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
+        xf[4] += dv[2];
+      }
+      // covariance sweep  P_ij -= Lambda_ij (K_i . W_j)   (:256-257, or :264-265 with Lambda = 1)
+      const long tot = (long)nact * nact;
+      for (long e = tid; e < tot; e += T) {
+        const int i = (int)(e % nact), j = (int)(e / nact);
+        const double t = K[2 * i] * W[2 * j] + K[2 * i + 1] * W[2 * j + 1];
+        const double li = lam[i], lj = lam[j];
+        const double L = partial ? (lj + li - li * lj) : 1.0;
+        P[i + (long)j * ld] -= L * t;
+      }
+    }
+    __syncthreads();
+    for (int f = tid; f < len; f += T) fix_depth_one(xs, P, ld, f, a.p, flag);   // :271
+    if (res && tid == 0) *res = 0;
+    __syncthreads();
+  }
+  for (int i = tid; i < xZ + 5 * len; i += T) {
+    const double v = xs[i];
+    if (v != v) flag |= FLAG_NAN;
+    if (v > 1e6) flag |= FLAG_BLOWUP;
+    xg[i] = v;
+  }
+  if (flag) atomicOr(&a.flags[b], flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// init_feature (vi_ekf_feat.cpp:6-47), one workgroup per filter
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_init_feature(StreamArgs a, const double* __restrict__ pix_all,
+                                                    const double* __restrict__ depth_all,
+                                                    const unsigned char* __restrict__ mask, int* __restrict__ ok) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  if (mask && !mask[b]) { if (ok && tid == 0) ok[b] = 0; return; }
+  const int len = a.len[b];
+  if (len >= a.N) { if (ok && tid == 0) ok[b] = 0; return; }   // :9-10
+  const int n = a.n, ld = a.ld;
+  double* P = a.P + (long)b * n * ld;
+  const int d0 = 16 + 3 * len, dmax = d0 + 3;
+  if (tid == 0) {
+    double q[4], rho;
+    init_feature_state(pix_all + 2L * b, depth_all ? depth_all[b] : NAN, a.p, q, &rho);
+    double* xf = a.x + (long)b * a.nxs + xZ + 5 * len;
+    xf[0] = q[0]; xf[1] = q[1]; xf[2] = q[2]; xf[3] = q[3]; xf[4] = rho;
+  }
+  // zero the cross strips, set the 3x3 block to P0_feat (:39-42)
+  for (int e = tid; e < 3 * d0; e += T) {
+    const int j = e / 3, r = e % 3;
+    P[(d0 + r) + (long)j * ld] = 0.0;
+    P[j + (long)(d0 + r) * ld] = 0.0;
+  }
+  if (tid < 9) {
+    const int r = tid % 3, c = tid / 3;
+    P[(d0 + r) + (long)(d0 + c) * ld] = (r == c) ? a.p.P0_feat[r] : 0.0;
+  }
+  (void)dmax;
+  __syncthreads();
+  if (tid == 0) {
+    a.len[b] = len + 1;
+    if (ok) ok[b] = 1;
+  }
+}
+
+// fill every filter with the initial state (vi_ekf.cpp:70-81 / :134-144)
+__global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, const double* __restrict__ Pdiag /*n*/) {
+  const int b = blockIdx.x;
+  if (b >= a.B) return;
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * a.n * a.ld;
+  for (int i = threadIdx.x; i < a.nxs; i += blockDim.x) xg[i] = (i < 17) ? x0[i] : 0.0;
+  const long tot = (long)a.n * a.ld;
+  for (long e = threadIdx.x; e < tot; e += blockDim.x) {
+    const int i = (int)(e % a.ld), j = (int)(e / a.ld);
+    P[e] = (i == j) ? Pdiag[i] : 0.0;
+  }
+  if (threadIdx.x == 0) { a.len[b] = 0; a.flags[b] = 0; }
+}
+
+}  // namespace viekf
