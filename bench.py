@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF steps/s of the batched VI-EKF hot path on MI355X.
+
+One "step" of one filter = one propagate (dt = 4 ms) + N_feat sequential active pixel updates
+(SURVEY.md 8d).  Default workload = BASELINE.json headline: batch 1024 filters x N_feat 50 per
+GPU.  Filters are independent, so N GPUs run N x batch filters with no data-path collective
+(weak scaling); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the
+reference's dense algorithm, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def shard(total, world, rank):
+    """contiguous partition of `total` filters: rank r owns [lo, hi)  """
+    lo = total * rank // world
+    hi = total * (rank + 1) // world
+    return lo, hi
+
+
+def reduce_times(local_seconds, world):
+    """max over ranks of the timed-region seconds (RCCL/gloo all_reduce MAX of one double)"""
+    if world == 1:
+        return local_seconds
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline_and_parity(sc, N, params, gpu_x, gpu_P, steps_cmp, n_filters, threads):
+    """Time the oracle on `n_filters` filters x `steps_cmp` steps of the SAME inputs and compare
+    with the GPU state after the same steps.  Checker/baseline only -- never the product path."""
+    from oracle import oracle as orc
+    keys = ("x0", "P0", "Qx", "lam", "Qu", "P0_feat", "Qx_feat", "lam_feat", "cam_center", "focal_len", "q_b_c",
+            "p_b_c", "q_b_u", "min_depth", "use_drag_term", "use_partial_update", "use_keyframe_reset")
+    fs = []
+    for b in range(n_filters):
+        f = orc.OracleFilter(N).init(**{k: params[k] for k in keys})
+        for i in range(N):
+            f.init_feature(sc["pix"][b, i], i)
+        fs.append(f)
+    u = np.ascontiguousarray(sc["u"][:steps_cmp, :n_filters].transpose(1, 0, 2))
+    z = np.ascontiguousarray(sc["z"][:steps_cmp, :n_filters].transpose(1, 0, 2, 3))
+    t0 = time.perf_counter()
+    orc.run_steps_mt(fs, threads, u, float(sc["dt"][0]), z, sc["slot"][:n_filters], sc["R"])
+    secs = time.perf_counter() - t0
+    xr = np.stack([f.x for f in fs])
+    Pr = np.stack([f.P for f in fs])
+    ex = float(np.abs(gpu_x[:n_filters] - xr).max() / np.abs(xr).max())
+    eP = float(np.abs(gpu_P[:n_filters] - Pr).max() / np.abs(Pr).max())
+    return n_filters * steps_cmp / secs, secs, max(ex, eP)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="filters per GPU")
+    ap.add_argument("--feat", type=int, default=50, help="N_feat")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-filters", type=int, default=0)
+    ap.add_argument("--cpu-steps", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vi_ekf_amd as v
+    from vi_ekf_amd import scene
+
+    B, N, K, W = args.batch, args.feat, args.steps, args.warmup
+    total_steps = K + W
+    lo, hi = shard(B * world, world, rank)
+    assert hi - lo == B
+    # synthetic inputs of this rank's filters (seeded per rank so every rank has different filters)
+    uniq = min(total_steps, 32)  # distinct input frames, cycled: keeps staging small at N=150
+    sc = scene.make_scene(B, N, uniq, seed=0x5EED0000 + rank)
+    params = sc["params"]
+
+    g = v.BatchVIEKF(B, N, params, device=local_rank)
+    if args.kernel:
+        g.set_kernel(args.kernel)
+    g.use_torch_stream()
+    d_u = torch.tensor(sc["u"], device=dev)
+    d_z = torch.tensor(sc["z"], device=dev)
+    d_dt = torch.tensor(sc["dt"], device=dev)
+    d_slot = torch.tensor(sc["slot"], device=dev)
+    d_R = torch.tensor(sc["R"], device=dev)
+    d_res = torch.empty((B, N), dtype=torch.int32, device=dev)
+    d_pix = torch.tensor(np.ascontiguousarray(sc["pix"].transpose(1, 0, 2)), device=dev)  # [N][B][2]
+    d_nan = torch.full((B,), float("nan"), dtype=torch.float64, device=dev)
+
+    def init_filters():
+        g.reset()
+        for i in range(N):
+            g.init_feature(d_pix[i], d_nan)
+
+    def step(s):
+        g.step(d_u[s % uniq], d_dt, d_z[s % uniq], d_slot, d_R, result=d_res)
+
+    # ---- phase A (rank 0, N=1 run only): parity vs the oracle + CPU baseline on a bounded sample
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 16)
+        nf = args.cpu_filters or min(B, 8 * threads)
+        # keep the sample at ~10-30 s of CPU work: dense cost ~ (8 + 4N) n^3 flop per filter-step,
+        # assuming ~6 GFLOP/s per thread for the plain-C dense loops; capped by the distinct frames
+        n = 16 + 3 * N
+        flop = (8 + 4 * N) * float(n) ** 3
+        sc_steps = args.cpu_steps or int(max(1, min(uniq, round(15.0 * 6.0e9 * threads / (flop * nf)))))
+        init_filters()
+        for s in range(sc_steps):
+            step(s)
+        torch.cuda.synchronize()
+        gx, gP = g.get_state(), g.get_covariance()
+        rate, secs, err = cpu_baseline_and_parity(sc, N, params, gx, gP, sc_steps, nf, threads)
+        cpu = {"value": rate, "unit": "EKF steps/s", "cores": threads, "kind": "port",
+               "sample": "%d filters x %d steps of the same inputs, dense reference-order oracle, %.1f s wall"
+                         % (nf, sc_steps, secs)}
+        parity = err
+        if err > 1e-6:
+            raise SystemExit("PARITY FAILURE vs oracle: rel err %.3e" % err)
+
+    # ---- phase B: warmup + timed region
+    init_filters()
+    for s in range(W):
+        step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for s in range(K):
+        step(W + s)
+        ev[s + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    secs = reduce_times(secs, world)
+    status = g.get_status()
+    n_bad = int((status & 1).sum())
+
+    # per-launch duration of the step's kernels from HIP events on the launch stream
+    launch_ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
+    launch_s = float(np.median(launch_ms)) * 1e-3
+    alg_bytes = scene.algorithmic_bytes_per_step(N) * B  # one launch processes B filter-steps
+    achieved = alg_bytes / launch_s / 1e9
+
+    if rank == 0:
+        total_filters = B * world
+        out = {
+            "metric": "EKF steps/sec (IMU-rate propagate + N_feat updates), batch=%d, N_feat=%d" % (B, N),
+            "value": total_filters * K / secs,
+            "unit": "EKF steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": secs / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "batch=%d filters per GPU, N_feat=%d (n=%d), static-hover synthetic IMU+pixels, "
+                                   "1 propagate + %d active FEAT updates per step" % (B, N, 16 + 3 * N, N),
+                       "batch_per_gpu": B, "n_feat": N, "parallelism": "filters sharded %d-way, no collective" % world,
+                       "kernel_family": args.kernel},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step launch group (propagate + update), median HIP-event duration %.4f ms" % (launch_s * 1e3),
+                         "alg_bytes_per_launch": alg_bytes},
+            "nan_filters": n_bad,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["parity_max_rel_err"] = parity
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

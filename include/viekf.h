@@ -111,7 +111,8 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params *
 int viekf_batch_destroy(viekf_batch *b);
 int viekf_batch_reset(viekf_batch *b);    /* back to the state viekf_batch_create left */
 int viekf_batch_dims(const viekf_batch *b, int32_t *batch, int32_t *num_features, int32_t *nx, int32_t *n);
-/* run all later calls of this batch on an existing hipStream_t (e.g. torch's current stream); NULL = own stream */
+/* run all later calls of this batch on a caller-owned hipStream_t (e.g. torch's current stream);
+ * NULL = HIP's default (null) stream.  A new batch starts on a private non-blocking stream. */
 int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
 int viekf_batch_sync(viekf_batch *b);
 /* kernel family: 0 = auto, 1 = streaming (P in HBM/L2, any num_features), 2 = resident (P on chip) */

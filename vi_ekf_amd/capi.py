@@ -82,6 +82,15 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.LIB
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7.  If it is loaded first,
+        # our NEEDED libamdhip64.so.7 binds to that copy (same SONAME) and device pointers / streams
+        # can be shared with torch; loaded the other way round the process ends up with two runtimes
+        # and torch reports "No HIP GPUs are available".
+        if os.environ.get("VIEKF_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(path):
             raise ImportError("libviekf_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                               "vi_ekf_amd has no CPU fallback")

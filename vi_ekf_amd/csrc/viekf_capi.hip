@@ -320,13 +320,9 @@ int viekf_batch_set_stream(viekf_batch* b, void* hip_stream) {
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (b->own_stream && b->stream) { HIP_TRY(hipStreamDestroy(b->stream)); b->stream = nullptr; b->own_stream = false; }
-  if (hip_stream) {
-    b->stream = static_cast<hipStream_t>(hip_stream);
-    b->own_stream = false;
-  } else {
-    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    b->own_stream = true;
-  }
+  // NULL is HIP's default (null) stream, exactly as a hipStream_t of 0 means everywhere else
+  b->stream = static_cast<hipStream_t>(hip_stream);
+  b->own_stream = false;
   return VIEKF_OK;
 }
 
