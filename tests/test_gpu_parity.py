@@ -55,8 +55,10 @@ def run_oracle(sc, B, N, steps, nfeat=None):
     return x, P, res
 
 
-def make_gpu(sc, B, N, nfeat=None):
+def make_gpu(sc, B, N, nfeat=None, kernel=0):
     g = v.BatchVIEKF(B, N, sc["params"])
+    if kernel:
+        g.set_kernel(kernel)
     nfeat = N if nfeat is None else nfeat
     for i in range(nfeat):
         ok = g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
@@ -64,11 +66,14 @@ def make_gpu(sc, B, N, nfeat=None):
     return g
 
 
-@pytest.mark.parametrize("B,N,steps", [(3, 3, 6), (4, 12, 5), (2, 25, 3), (2, 50, 2)])
-def test_step_parity(B, N, steps):
+# kernel 1 = streaming family (P in HBM/L2), 2 = resident family (P in registers, N in 8..50)
+@pytest.mark.parametrize("B,N,steps,kernel", [(3, 3, 6, 1), (4, 12, 5, 1), (2, 25, 3, 1), (2, 50, 2, 1),
+                                              (4, 8, 4, 2), (4, 12, 5, 2), (3, 17, 3, 2), (2, 25, 3, 2),
+                                              (2, 33, 2, 2), (2, 41, 2, 2), (3, 50, 2, 2)])
+def test_step_parity(B, N, steps, kernel):
     sc = scene.make_scene(B, N, steps, seed=100 + N)
     x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)
-    g = make_gpu(sc, B, N)
+    g = make_gpu(sc, B, N, kernel=kernel)
     res = np.zeros_like(res_ref)
     for s in range(steps):
         res[s] = g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
@@ -91,9 +96,10 @@ def test_init_state_matches_oracle():
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after init_feature")
 
 
-def test_propagate_only_partial_features_and_qx():
+@pytest.mark.parametrize("N,nfeat", [(6, 4), (12, 7), (26, 20)])
+def test_propagate_only_partial_features_and_qx(N, nfeat):
     """inactive slots still receive Qx_feat (reference vi_ekf.cpp:139-144,304); drag term off; Qx != 0"""
-    B, N, nfeat = 3, 6, 4
+    B = 3
     over = dict(Qx=[1e-4] * 16, Qx_feat=[1e-5, 2e-5, 3e-5], use_drag_term=0)
     sc = scene.make_scene(B, N, 4, seed=11, params=over)
     g = make_gpu(sc, B, N, nfeat=nfeat)
@@ -111,9 +117,10 @@ def test_propagate_only_partial_features_and_qx():
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-def test_update_gating_nan_invalid_and_full_update():
+@pytest.mark.parametrize("N", [4, 9])
+def test_update_gating_nan_invalid_and_full_update(N):
     """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update"""
-    B, N = 4, 4
+    B = 4
     sc = scene.make_scene(B, N, 1, seed=21, params=dict(use_partial_update=0))
     g = make_gpu(sc, B, N)
     fs = []
@@ -150,9 +157,10 @@ def test_update_gating_nan_invalid_and_full_update():
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-def test_fix_depth_branches():
+@pytest.mark.parametrize("N", [3, 10])
+def test_fix_depth_branches(N):
     """force rho < 0 and rho > 1e2 (reference vi_ekf_helper.cpp:128-156): a rare branch needs its own test"""
-    B, N = 2, 3
+    B = 2
     sc = scene.make_scene(B, N, 1, seed=31)
     g = make_gpu(sc, B, N)
     x = g.get_state()

@@ -81,7 +81,7 @@ class ViekfError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        path = _build.LIB
+        path = os.environ.get("VIEKF_LIB") or _build.LIB
         # One HIP runtime per process: torch ships its own libamdhip64.so.7.  If it is loaded first,
         # our NEEDED libamdhip64.so.7 binds to that copy (same SONAME) and device pointers / streams
         # can be shared with torch; loaded the other way round the process ends up with two runtimes

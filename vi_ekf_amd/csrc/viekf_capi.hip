@@ -10,7 +10,7 @@
 
 #include "../../include/viekf.h"
 #include "viekf_host.hpp"
-#include "viekf_kernels_stream.hpp"
+#include "viekf_kernels_resident.hpp"
 
 using namespace viekf;
 
@@ -46,8 +46,12 @@ struct viekf_batch {
   long ws_stride = 0;
   char* d_stage = nullptr;
   size_t stage_bytes = 0, stage_used = 0;
-  int family = 0;
+  int family = 0;       // requested: 0 auto, 1 streaming, 2 resident
+  int res_inst = -1;    // resident instance index (-1: N not covered by the resident family)
+  int res_TR = 0, res_TC = 0;
+  size_t res_lds = 0;
   DevParams dp;
+  DevParams* d_dp = nullptr;
 };
 
 namespace {
@@ -58,7 +62,7 @@ StreamArgs make_args(const viekf_batch* b) {
   a.Qx = b->d_Qx; a.lambda = b->d_lambda; a.ws = b->d_ws;
   a.B = b->B; a.N = b->N; a.nx = b->nx; a.nxs = b->nxs; a.n = b->n; a.ld = b->ld;
   a.ws_stride = b->ws_stride;
-  a.p = b->dp;
+  a.dp = b->d_dp;
   return a;
 }
 
@@ -124,6 +128,64 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
   hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
                      d_slot, M, d_R, rsb, rsm, d_res);
+  HIP_TRY(hipGetLastError());
+  return VIEKF_OK;
+}
+
+// Resident instances <RB, CB, T, SI, SJ>: thread grid TR = ceil(N/RB) x TC = ceil(N/CB) must fit T threads and the
+// body-strip pieces per thread (RB*16/TC, CB*16/TR) must fit SI, SJ.
+struct ResInst { int RB, CB, T, SI, SJ, nmin, nmax; };
+const ResInst kResInst[] = {
+    {5, 1, 512, 2, 2, 40, 50},
+    {4, 1, 512, 2, 2, 32, 39},
+    {3, 1, 512, 2, 2, 24, 31},
+    {2, 1, 512, 2, 2, 16, 23},
+    {1, 1, 256, 2, 2, 8, 15},
+};
+
+typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int,
+                             const double*, long, long, int*);
+res_kernel_t res_kernel(int inst) {
+  switch (inst) {
+    case 0: return k_step_resident<5, 1, 512, 2, 2>;
+    case 1: return k_step_resident<4, 1, 512, 2, 2>;
+    case 2: return k_step_resident<3, 1, 512, 2, 2>;
+    case 3: return k_step_resident<2, 1, 512, 2, 2>;
+    case 4: return k_step_resident<1, 1, 256, 2, 2>;
+  }
+  return nullptr;
+}
+
+int setup_resident(viekf_batch* b) {
+  b->res_inst = -1;
+  for (int i = 0; i < (int)(sizeof(kResInst) / sizeof(kResInst[0])); i++) {
+    const ResInst& r = kResInst[i];
+    if (b->N < r.nmin || b->N > r.nmax) continue;
+    const int TR = (b->N + r.RB - 1) / r.RB, TC = (b->N + r.CB - 1) / r.CB;
+    if (TR * TC > r.T) continue;
+    if ((r.RB * 16 + TC - 1) / TC > r.SI || (r.CB * 16 + TR - 1) / TR > r.SJ) continue;
+    const ResLds L(b->N, b->n, b->nxs);
+    const size_t lds = sizeof(double) * (size_t)L.total;
+    if (lds > 160 * 1024) continue;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
+    break;
+  }
+  return VIEKF_OK;
+}
+
+bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family != 1; }
+
+int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
+                    const int* d_slot, int M, const double* d_R, int r_mode, int* d_res) {
+  StreamArgs a = make_args(b);
+  long rsb = 0, rsm = 0;
+  if (r_mode == 1) rsb = 4;
+  else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
+  const ResInst& r = kResInst[b->res_inst];
+  hipLaunchKernelGGL(res_kernel(b->res_inst), dim3(b->B), dim3(r.T), b->res_lds, b->stream, a, b->res_TR, b->res_TC,
+                     do_prop ? 1 : 0, d_u, d_dt, d_z, d_slot, M, d_R, rsb, rsm, d_res);
   HIP_TRY(hipGetLastError());
   return VIEKF_OK;
 }
@@ -251,6 +313,7 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   ALLOC(b->d_ws, sizeof(double) * (size_t)batch * b->ws_stride);
   ALLOC(b->d_len, sizeof(int) * (size_t)batch);
   ALLOC(b->d_flags, sizeof(unsigned) * (size_t)batch);
+  ALLOC(b->d_dp, sizeof(DevParams));
 #undef ALLOC
   hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -275,6 +338,8 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   up(b->d_lambda, lam.data(), b->n);
   up(b->d_Pdiag, Pd.data(), b->n);
   up(b->d_x0, p->x0, 17);
+  if (hipMemcpy(b->d_dp, &b->dp, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess) rc = VIEKF_ERR_HIP;
+  if (rc == VIEKF_OK) rc = setup_resident(b);
   if (rc == VIEKF_OK) rc = viekf_batch_reset(b);
   if (rc != VIEKF_OK) {
     viekf_batch_destroy(b);
@@ -288,7 +353,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage};
+  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -336,7 +401,8 @@ int viekf_batch_sync(viekf_batch* b) {
 int viekf_batch_set_kernel(viekf_batch* b, int32_t family) {
   if (int rc = check_batch(b)) return rc;
   if (family < 0 || family > 2) return fail(VIEKF_ERR_INVALID, "kernel family must be 0, 1 or 2");
-  if (family == 2) return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family not available in this build");
+  if (family == 2 && b->res_inst < 0)
+    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (8..50)");
   b->family = family;
   return VIEKF_OK;
 }
@@ -395,7 +461,11 @@ int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, vie
     if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B))) return rc;
   if (int rc = in_ptr(b, u, (size_t)6 * b->B, where, &d_u)) return rc;
   if (int rc = in_ptr(b, dt, (size_t)b->B, where, &d_dt)) return rc;
-  if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+  if (use_resident(b)) {
+    if (int rc = launch_resident(b, true, d_u, d_dt, nullptr, nullptr, 0, nullptr, 0, nullptr)) return rc;
+  } else {
+    if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+  }
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
@@ -457,10 +527,15 @@ static int update_or_step(viekf_batch* b, const double* u, const double* dt, boo
     if (int rc = in_ptr(b, R, r_count(b, M, r_mode), where, &d_R)) return rc;
     if (result) d_res = where == VIEKF_DEVICE ? result : static_cast<int32_t*>(stage_take(b, sizeof(int32_t) * BM));
   }
-  if (with_propagate)
-    if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
-  if (M > 0)
-    if (int rc = launch_update(b, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
+  if (use_resident(b)) {
+    if (with_propagate || M > 0)
+      if (int rc = launch_resident(b, with_propagate, d_u, d_dt, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
+  } else {
+    if (with_propagate)
+      if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+    if (M > 0)
+      if (int rc = launch_update(b, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
+  }
   if (where == VIEKF_HOST) {
     if (result && M > 0) HIP_TRY(hipMemcpyAsync(result, d_res, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));

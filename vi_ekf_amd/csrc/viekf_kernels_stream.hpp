@@ -24,7 +24,7 @@ struct StreamArgs {
   double* ws;           // [B][ws_stride]
   int B, N, nx, nxs, n, ld;
   long ws_stride;
-  DevParams p;
+  const DevParams* dp;  // device memory (uniform loads); NOT by value: indexing a by-value kernarg array spills it to scratch
 };
 
 // workspace carve-up (doubles) for one filter
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
 
   if (tid == 0) {
     double ub[6];
-    q_rota(a.p.q_b_u, u_all + (long)b * 6, ub);          // vi_ekf.cpp:265-267
-    q_rota(a.p.q_b_u, u_all + (long)b * 6 + 3, ub + 3);
-    body_ctx(xs, ub, a.p, *ctx);
-    body_dynamics(*ctx, a.p, xdb, Abb, Gb);               // vi_ekf_dyn.cpp:42-80
+    q_rota(a.dp->q_b_u, u_all + (long)b * 6, ub);          // vi_ekf.cpp:265-267
+    q_rota(a.dp->q_b_u, u_all + (long)b * 6 + 3, ub + 3);
+    body_ctx(xs, ub, (*a.dp), *ctx);
+    body_dynamics(*ctx, (*a.dp), xdb, Abb, Gb);               // vi_ekf_dyn.cpp:42-80
   }
   __syncthreads();
 
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     }
     double gacc[18];
     for (int e = 0; e < 18; e++) gacc[e] = 0.0;
+#pragma unroll
     for (int c = 0; c < 16; c++) {
+#pragma unroll
       for (int r = 0; r < 3; r++) {
         // A_fb(r,c): non-zero only in the VEL and B_G columns
         double afb = 0.0;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     double s = 0.0;
     for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
     double g = 0.0;
-    for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * a.p.Qu[k] * Gdb[c * 6 + k];
+    for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * a.dp->Qu[k] * Gdb[c * 6 + k];
     s = s + g;
     if (r == c) s += a.Qx[r];
     P[r + (long)c * ld] = s;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
       st += Phibb[k * 16 + c] * Ut[c * nf + r];
     }
     double g = 0.0;
-    for (int q = 0; q < 6; q++) g += gd[(16 + r) * 6 + q] * a.p.Qu[q] * Gdb[k * 6 + q];
+    for (int q = 0; q < 6; q++) g += gd[(16 + r) * 6 + q] * a.dp->Qu[q] * Gdb[k * 6 + q];
     P[(16 + r) + (long)k * ld] = s + g;
     P[k + (long)(16 + r) * ld] = st + g;
   }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
         for (int k = 0; k < 16; k++) s += U[(3 * I + r) * 16 + k] * phi_fb[(3 * J + c) * 16 + k];
         for (int m = 0; m < 3; m++) s += Mij[r * 3 + m] * phi_ff[9 * J + c * 3 + m];
         double g = 0.0;
-        for (int q = 0; q < 6; q++) g += gd[(r0 + r) * 6 + q] * a.p.Qu[q] * gd[(c0 + c) * 6 + q];
+        for (int q = 0; q < 6; q++) g += gd[(r0 + r) * 6 + q] * a.dp->Qu[q] * gd[(c0 + c) * 6 + q];
         s = s + g;
         if (I == J && r == c) s += a.Qx[r0 + r];
         out[r * 3 + c] = s;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
 
   // ---- fix_depth (vi_ekf.cpp:311) and write the state back
   unsigned flag = 0;
-  for (int i = tid; i < len; i += T) fix_depth_one(xs, P, ld, i, a.p, flag);
+  for (int i = tid; i < len; i += T) fix_depth_one(xs, P, ld, i, (*a.dp), flag);
   __syncthreads();
   for (int i = tid; i < xZ + 5 * len; i += T) {
     const double v = xs[i];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
     const int j0 = 16 + 3 * slot;
     if (tid == 0) {
       double zhat[2], Hb[4];
-      h_feat(xs + xZ + 5 * slot, a.p, zhat, Hb);
+      h_feat(xs + xZ + 5 * slot, (*a.dp), zhat, Hb);
       sm[0] = zhat[0]; sm[1] = zhat[1];
       sm[2] = Hb[0]; sm[3] = Hb[1]; sm[4] = Hb[2]; sm[5] = Hb[3];
       sm[6] = z0 - zhat[0]; sm[7] = z1 - zhat[1];      // residual (vi_ekf_meas.cpp:220)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
     if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
     bad = __syncthreads_or(bad);
     if (!bad) {
-      const bool partial = a.p.use_partial_update != 0;
+      const bool partial = a.dp->use_partial_update != 0;
       // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263)
       if (tid == 0) {
         double dxb[16], xo[17];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
       }
     }
     __syncthreads();
-    for (int f = tid; f < len; f += T) fix_depth_one(xs, P, ld, f, a.p, flag);   // :271
+    for (int f = tid; f < len; f += T) fix_depth_one(xs, P, ld, f, (*a.dp), flag);   // :271
     if (res && tid == 0) *res = 0;
     __syncthreads();
   }
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(T) void k_init_feature(StreamArgs a, const double* 
   const int d0 = 16 + 3 * len, dmax = d0 + 3;
   if (tid == 0) {
     double q[4], rho;
-    init_feature_state(pix_all + 2L * b, depth_all ? depth_all[b] : NAN, a.p, q, &rho);
+    init_feature_state(pix_all + 2L * b, depth_all ? depth_all[b] : NAN, (*a.dp), q, &rho);
     double* xf = a.x + (long)b * a.nxs + xZ + 5 * len;
     xf[0] = q[0]; xf[1] = q[1]; xf[2] = q[2]; xf[3] = q[3]; xf[4] = rho;
   }
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(T) void k_init_feature(StreamArgs a, const double* 
   }
   if (tid < 9) {
     const int r = tid % 3, c = tid / 3;
-    P[(d0 + r) + (long)(d0 + c) * ld] = (r == c) ? a.p.P0_feat[r] : 0.0;
+    P[(d0 + r) + (long)(d0 + c) * ld] = (r == c) ? a.dp->P0_feat[r] : 0.0;
   }
   (void)dmax;
   __syncthreads();
