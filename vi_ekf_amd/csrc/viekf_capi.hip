@@ -132,26 +132,18 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   return VIEKF_OK;
 }
 
-// Resident instances <RB, CB, T, SI, SJ>: thread grid TR = ceil(N/RB) x TC = ceil(N/CB) must fit T threads and the
-// body-strip pieces per thread (RB*16/TC, CB*16/TR) must fit SI, SJ.
-struct ResInst { int RB, CB, T, SI, SJ, nmin, nmax; };
+// Resident instances <RB, CB, NW>: NW worker waves (+1 service wave) per workgroup; the worker thread grid
+// TR = ceil(N/RB) x TC = ceil(N/CB) must fit NW*64 threads.
+struct ResInst { int RB, CB, NW, nmin, nmax; };
 const ResInst kResInst[] = {
-    {5, 1, 512, 2, 2, 40, 50},
-    {4, 1, 512, 2, 2, 32, 39},
-    {3, 1, 512, 2, 2, 24, 31},
-    {2, 1, 512, 2, 2, 16, 23},
-    {1, 1, 256, 2, 2, 8, 15},
+    {3, 2, 7, 1, 50},
 };
 
-typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int,
+typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
                              const double*, long, long, int*);
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
-    case 0: return k_step_resident<5, 1, 512, 2, 2>;
-    case 1: return k_step_resident<4, 1, 512, 2, 2>;
-    case 2: return k_step_resident<3, 1, 512, 2, 2>;
-    case 3: return k_step_resident<2, 1, 512, 2, 2>;
-    case 4: return k_step_resident<1, 1, 256, 2, 2>;
+    case 0: return k_step_resident<3, 2, 7>;
   }
   return nullptr;
 }
@@ -162,8 +154,7 @@ int setup_resident(viekf_batch* b) {
     const ResInst& r = kResInst[i];
     if (b->N < r.nmin || b->N > r.nmax) continue;
     const int TR = (b->N + r.RB - 1) / r.RB, TC = (b->N + r.CB - 1) / r.CB;
-    if (TR * TC > r.T) continue;
-    if ((r.RB * 16 + TC - 1) / TC > r.SI || (r.CB * 16 + TR - 1) / TR > r.SJ) continue;
+    if (TR * TC > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > 160 * 1024) continue;
@@ -177,6 +168,7 @@ int setup_resident(viekf_batch* b) {
 
 bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family != 1; }
 
+// one launch handles at most MCAP measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res) {
   StreamArgs a = make_args(b);
@@ -184,9 +176,16 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
   const ResInst& r = kResInst[b->res_inst];
-  hipLaunchKernelGGL(res_kernel(b->res_inst), dim3(b->B), dim3(r.T), b->res_lds, b->stream, a, b->res_TR, b->res_TC,
-                     do_prop ? 1 : 0, d_u, d_dt, d_z, d_slot, M, d_R, rsb, rsm, d_res);
-  HIP_TRY(hipGetLastError());
+  int m0 = 0;
+  do {
+    const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
+    hipLaunchKernelGGL(res_kernel(b->res_inst), dim3(b->B), dim3((r.NW + 1) * 64), b->res_lds, b->stream, a, b->res_TR,
+                       b->res_TC, (do_prop && m0 == 0) ? 1 : 0, d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
+                       d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
+                       d_res ? d_res + m0 : nullptr);
+    HIP_TRY(hipGetLastError());
+    m0 += mc;
+  } while (m0 < M);
   return VIEKF_OK;
 }
 
@@ -402,7 +401,7 @@ int viekf_batch_set_kernel(viekf_batch* b, int32_t family) {
   if (int rc = check_batch(b)) return rc;
   if (family < 0 || family > 2) return fail(VIEKF_ERR_INVALID, "kernel family must be 0, 1 or 2");
   if (family == 2 && b->res_inst < 0)
-    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (8..50)");
+    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (1..50)");
   b->family = family;
   return VIEKF_OK;
 }

@@ -25,21 +25,22 @@ namespace viekf {
 constexpr int XK = 38;  // contraction depth of the propagate GEMM: 16 (U) + 16 (Phi_fb) + 6 (Gd)
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, Pbr, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, mslot, mz, mR, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
     Kt = take(2 * n); Wt = take(2 * n); Praw = take(2 * n); lam = take(n);
-    sm = take(32);
+    sm = take(48);   // [0..15] two prediction mailboxes, [28..29] fix mailboxes non-empty, [30] dt, [31] gate verdict, [32..47] body dx
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
     X = take(nf * XK); Y = take(nf * XK);
     phiff = take(9 * (N > 0 ? N : 1));
     Abb = take(256); Gb = take(96); Phibb = take(256); Mbb = take(256); Gdb = take(96); Pbb = take(256);
     T16 = take(256); xdb = take(16);
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
-    Pbc = take(nf * 16); Pbr = take(16 * nf);
+    Pbc = take(nf * 16);
+    mslot = take(32); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
 };
@@ -190,7 +191,7 @@ __device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* 
 // state correction of one feature + fix_depth + (optionally) the next measurement's prediction
 __device__ RES_INLINE void res_feature_update(double* xf, bool do_corr, bool do_fix, double d0, double d1, double d2,
                                                 const DevParams* p, double* fixadd_slot, double* fixset_slot,
-                                                unsigned* flag, const double* z_next, double* smw) {
+                                                double* fixany, unsigned* flag, const double* z_next, double* smw) {
   if (do_corr) {
     double qn[4];
     q_feat_boxplus_fast(xf, d0, d1, qn);
@@ -204,10 +205,12 @@ __device__ RES_INLINE void res_feature_update(double* xf, bool do_corr, bool do_
     if (rho < 0.0) {
       const double err = reset - rho;
       *fixadd_slot = err * err;
+      *fixany = 1.0;
       rho = reset;
       *flag |= FLAG_NEGDEPTH;
     } else if (rho > 1e2) {
       *fixset_slot = 1.0;
+      *fixany = 1.0;
       rho = reset;
     }
     xf[4] = rho;
@@ -234,225 +237,180 @@ __device__ RES_INLINE void res_body_update(double* xs, const double* Kt, const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused step: [propagate] + M feature updates with P resident in registers
+// fused step: [propagate] + M feature updates with P resident in registers, WARP-SPECIALISED:
+//   worker waves (NW x 64 threads) own P and run only the lean contraction / sweep code;
+//   one service wave runs the scalar-heavy math (dynamics, gain, manifold correction, h_feat).
+// Both sides execute the same barrier sequence; their register footprints never mix, which is
+// what keeps the sweep loops spill-free (a spill costs a ~1 us scratch round trip per use).
 // ------------------------------------------------------------------------------------------------
-template <int RB, int CB, int T, int SI, int SJ>
-__global__ __launch_bounds__(T) void k_step_resident(StreamArgs a, int TR, int TC, int do_prop,
-                                                     const double* __restrict__ u_all,
-                                                     const double* __restrict__ dt_all,
-                                                     const double* __restrict__ z_all,
-                                                     const int* __restrict__ slot_all, int M,
-                                                     const double* __restrict__ R_all, long r_stride_b, long r_stride_m,
-                                                     int* __restrict__ result_all) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int BBE = 1;  // P_bb: one element per thread, threads 0..255
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (b >= a.B) return;
-  const int N = a.N, n = a.n, ld = a.ld, nf = 3 * N;
-  const ResLds L(N, n, a.nxs);
-  double* xs = smem + L.xs;
-  double* Kt = smem + L.Kt;
-  double* Wt = smem + L.Wt;
-  double* Praw = smem + L.Praw;
-  double* lam = smem + L.lam;
-  double* sm = smem + L.sm;
-  double* fixadd = smem + L.fixadd;
-  double* fixset = smem + L.fixset;
-  double* X = smem + L.X;
-  double* Y = smem + L.Y;
-  double* phiff = smem + L.phiff;
-  double* Pbb = smem + L.Pbb;
+// Returns v unchanged but opaque to the optimiser: values derived from it cannot be hoisted out of a loop and kept
+// (or spilled) across iterations; recomputing a few integer ops per use is far cheaper than a scratch round trip.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ double uniform_f64(double v) {   // force a wave-uniform double into SGPRs
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
-  const int len = a.len[b];
-  const int tr = tid % TR, tc = tid / TR;
-  const bool own = tid < TR * TC;
-  unsigned flag = 0;
+constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lists)
 
-  // ---------------- load x, lambda, P (registers) ----------------
-  for (int i = tid; i < a.nxs; i += T) xs[i] = (i < xZ + 5 * len) ? xg[i] : 0.0;
-  for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
-  for (int i = tid; i < 2 * N; i += T) { fixadd[i] = 0.0; fixset[i] = 0.0; }
+struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
+  double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
+      *xdb, *Pbc, *mz, *mR;
+  int* mslot;   // [MCAP] slot, or -(code+2) for a measurement that is not run (code -1/2/3 -> -1/-4/-5)
+  BodyCtx* ctx;
+  int N, n, nf, len, M, mstride, do_prop, b;
+};
+
+// first m' >= from whose update will actually run (mslot >= 0), else M
+__device__ __forceinline__ int res_next_valid(const ResShared& S, int from) {
+  int m = from;
+  while (m < S.M && S.mslot[m] < 0) m++;
+  return m;
+}
+
+template <int RB, int CB, int TW>
+__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TC, int tid) {
+  const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
+  double* P = a.P + (long)S.b * n * ld;
+  const int tr_ = tid % TR, tc_ = tid / TR;
+  const DevParams& prm = *a.dp;
+  double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
+  double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
+  // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
 
   double pb[RB][CB][9];   // pb[a][c][r*3+s] = P[16+3I+r][16+3J+s]
-  double sI[SI][3];       // P[16+3I+r][k]
-  double sJ[SJ][3];       // P[k][16+3J+s]
-  double sbb[BBE];        // P[r][c], e = tid + T*w, r = e & 15, c = e >> 4
+  {
+    // element (ia,ic,r,s) lives at  P + [uniform: (16+r+3 TR ia) + (16+s+3 TC ic) ld] + [per thread: 3 tr + 3 tc ld]
+    // loads are unconditional (branch-free): out-of-range owners read a valid element that is never used
+    const int tr = opaque(tr_), tc = opaque(tc_);
+    const bool own = tc < TC;
+    const int toff = 3 * tr + 3 * tc * ld;
 #pragma unroll
-  for (int ia = 0; ia < RB; ia++)
+    for (int ia = 0; ia < RB; ia++)
 #pragma unroll
-    for (int ic = 0; ic < CB; ic++) {
-      const int I = tr + TR * ia, J = tc + TC * ic;
-      const bool v = own && I < N && J < N;
+      for (int ic = 0; ic < CB; ic++) {
+        const int I = tr + TR * ia, J = tc + TC * ic;
+        const bool v = own && I < N && J < N;
+        const int tsel = v ? toff : 0;
 #pragma unroll
-      for (int s = 0; s < 3; s++)
+        for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int r = 0; r < 3; r++) pb[ia][ic][r * 3 + s] = v ? P[(16 + 3 * I + r) + (long)(16 + 3 * J + s) * ld] : 0.0;
+          for (int r = 0; r < 3; r++) {
+            const double* pu = P + (v ? ((16 + r + 3 * TR * ia) + (long)(16 + s + 3 * TC * ic) * ld) : 0L);
+            pb[ia][ic][r * 3 + s] = pu[tsel];
+          }
+      }
+    // body columns -> LDS (coalesced along rows)
+    for (int e = tid; e < nf * 16; e += TW) {
+      const int k = e / nf, row = e - k * nf;
+      Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
     }
-#pragma unroll
-  for (int q = 0; q < SI; q++) {
-    const int e = tc + TC * q, ia = e >> 4, k = e & 15, I = tr + TR * ia;
-    const bool v = own && e < RB * 16 && I < N;
-#pragma unroll
-    for (int r = 0; r < 3; r++) sI[q][r] = v ? P[(16 + 3 * I + r) + (long)k * ld] : 0.0;
+    for (int e = tid; e < 256; e += TW) Pbb[(e & 15) * 16 + (e >> 4)] = P[(e & 15) + (long)(e >> 4) * ld];
   }
-#pragma unroll
-  for (int q = 0; q < SJ; q++) {
-    const int e = tr + TR * q, ic = e >> 4, k = e & 15, J = tc + TC * ic;
-    const bool v = own && e < CB * 16 && J < N;
-#pragma unroll
-    for (int s = 0; s < 3; s++) sJ[q][s] = v ? P[k + (long)(16 + 3 * J + s) * ld] : 0.0;
-  }
-#pragma unroll
-  for (int w = 0; w < BBE; w++) {
-    const int e = tid + T * w;
-    sbb[w] = (e < 256) ? P[(e & 15) + (long)(e >> 4) * ld] : 0.0;
-  }
-  // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots)
+
+  // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots), kept in SGPRs
   double Lff[9];
   {
-    const double l0 = a.lambda[16 % n], l1 = a.lambda[17 % n], l2 = a.lambda[18 % n];
-    const double lf[3] = {l0, l1, l2};
+    const double lf[3] = {a.lambda[16], a.lambda[17], a.lambda[18]};
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int s = 0; s < 3; s++) Lff[r * 3 + s] = a.dp->use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0;
+      for (int s = 0; s < 3; s++) Lff[r * 3 + s] = uniform_f64(prm.use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0);
   }
-  __syncthreads();
+  const bool partial = prm.use_partial_update != 0;
+  int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  __syncthreads();  // B0
 
-  int fixpar = 0;  // parity of the fix_depth mailbox being WRITTEN in the current phase
+  if (S.do_prop) {
+    double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
+    double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
+    const double dt = S.sm[30];
+    __syncthreads();  // B1p : body Jacobian ready (service)
 
-  // =====================================================================================
-  // propagate (vi_ekf.cpp:262-318)
-  // =====================================================================================
-  if (do_prop) {
-    double* Abb = smem + L.Abb;
-    double* Gb = smem + L.Gb;
-    double* Phibb = smem + L.Phibb;
-    double* Mbb = smem + L.Mbb;
-    double* Gdb = smem + L.Gdb;
-    double* T16 = smem + L.T16;
-    double* xdb = smem + L.xdb;
-    BodyCtx* ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
-    double* Pbc = smem + L.Pbc;  // [nf][16]
-    double* Pbr = smem + L.Pbr;  // [16][nf]  (becomes Ut)
-    const double dt = dt_all[b];
-
-#ifndef ABL_BODY
-    if (tid == 0) res_body_phase(xs, u_all + (long)b * 6, a.dp, ctx, xdb, Abb, Gb);
-#endif
-    // strips -> LDS (inputs of U / Ut)
-#pragma unroll
-    for (int q = 0; q < SI; q++) {
-      const int e = tc + TC * q, ia = e >> 4, k = e & 15, I = tr + TR * ia;
-      if (own && e < RB * 16 && I < N)
-#pragma unroll
-        for (int r = 0; r < 3; r++) Pbc[(3 * I + r) * 16 + k] = sI[q][r];
-    }
-#pragma unroll
-    for (int q = 0; q < SJ; q++) {
-      const int e = tr + TR * q, ic = e >> 4, k = e & 15, J = tc + TC * ic;
-      if (own && e < CB * 16 && J < N)
-#pragma unroll
-        for (int s = 0; s < 3; s++) Pbr[k * nf + 3 * J + s] = sJ[q][s];
-    }
-#pragma unroll
-    for (int w = 0; w < BBE; w++) {
-      const int e = tid + T * w;
-      if (e < 256) Pbb[(e & 15) * 16 + (e >> 4)] = sbb[w];  // row-major copy
-    }
-    __syncthreads();
-
-    // body transition blocks
-    for (int e = tid; e < 256; e += T) {
+    for (int e = tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303)
       const int r = e >> 4, c = e & 15;
       double a2 = 0.0;
-      for (int k = 0; k < 16; k++) a2 += Abb[r * 16 + k] * Abb[k * 16 + c];
-      const double id = (r == c) ? 1.0 : 0.0, av = Abb[e];
+#pragma unroll 4
+      for (int k = 0; k < 16; k++) a2 += S.Abb[r * 16 + k] * S.Abb[k * 16 + c];
+      const double id = (r == c) ? 1.0 : 0.0, av = S.Abb[e];
       Mbb[e] = id + av * dt / 2.0 + a2 * dt * dt / 6.0;
       Phibb[e] = id + av * dt + a2 * dt * dt / 2.0;
     }
-    // per feature: dynamics -> Phi_fb (into X[.,16..31] and Y[.,0..15]), Phi_ff, Gd (X[.,32..37]*Qu, Y[.,32..37])
-#ifndef ABL_FEATP
-    for (int f = tid; f < N; f += T) res_feature_phase(f, len, dt, xs, ctx, a.dp, Abb, Gb, X, Y, phiff);
-#endif
-    __syncthreads();
-    if (tid == T - 1) {  // body state step (every feature thread has consumed the old body state)
-      double* kt = Kt;   // borrow Kt as [16][2] scratch: dx = xdot*dt in slot 0, 0 in slot 1
-      for (int i = 0; i < 16; i++) { kt[2 * i] = xdb[i] * dt; kt[2 * i + 1] = 0.0; }
-#ifndef ABL_BUPD
-      res_body_update(xs, kt, lam, false, 1.0, 0.0);
-#endif
-    }
-    for (int e = tid; e < 96; e += T) {
+    __syncthreads();  // B2p : Phi_fb / Phi_ff / Gd rows ready (service), Phi_bb ready (workers)
+
+    for (int e = tid; e < 96; e += TW) {
       const int r = e / 6, k = e % 6;
       double s = 0.0;
-      for (int c = 0; c < 16; c++) s += Mbb[r * 16 + c] * Gb[c * 6 + k];
+#pragma unroll 4
+      for (int c = 0; c < 16; c++) s += Mbb[r * 16 + c] * S.Gb[c * 6 + k];
       Gdb[e] = s * dt;
     }
-    for (int e = tid; e < 256; e += T) {
+    for (int e = tid; e < 256; e += TW) {
       const int r = e >> 4, c = e & 15;
       double s = 0.0;
+#pragma unroll 4
       for (int k = 0; k < 16; k++) s += Phibb[r * 16 + k] * Pbb[k * 16 + c];
       T16[e] = s;
     }
-    // U (-> X[.,0..15]) and V (-> Y[.,16..31]), Ut (in place over Pbr); one (block, k) triple per item
-    for (int e = tid; e < N * 16; e += T) {
+    // U = (Phi P)[feat, body] -> X[.,0..15];  V_J = Phi_ff[J] P[J, body] -> Y[.,16..31]
+#pragma unroll 1
+    for (int e = tid; e < N * 16; e += TW) {
       const int I = e >> 4, k = e & 15;
-      double pc[3], pr[3];
-      for (int m = 0; m < 3; m++) { pc[m] = Pbc[(3 * I + m) * 16 + k]; pr[m] = Pbr[k * nf + 3 * I + m]; }
+      double pc[3];
+#pragma unroll
+      for (int m = 0; m < 3; m++) pc[m] = Pbc[(3 * I + m) * 16 + k];
+#pragma unroll
       for (int r = 0; r < 3; r++) {
-        double su = 0.0, st = 0.0;
+        double su = 0.0;
         const double* phr = Y + (3 * I + r) * XK;  // Phi_fb[3I+r][0..15]
-        for (int c = 0; c < 16; c++) {
-          su += phr[c] * Pbb[c * 16 + k];
-          st += Pbb[k * 16 + c] * phr[c];
-        }
+#pragma unroll 4
+        for (int c = 0; c < 16; c++) su += phr[c] * Pbb[c * 16 + k];
         double sv = 0.0;
-        for (int m = 0; m < 3; m++) {
-          const double pf = phiff[9 * I + r * 3 + m];
-          su += pf * pc[m];
-          sv += pr[m] * pf;
-        }
-        X[(3 * I + r) * XK + k] = su;        // U
+#pragma unroll
+        for (int m = 0; m < 3; m++) sv += phiff[9 * I + r * 3 + m] * pc[m];
+        X[(3 * I + r) * XK + k] = su + sv;   // U
         Y[(3 * I + r) * XK + 16 + k] = sv;   // V
-        st += sv;
-        Pbr[k * nf + 3 * I + r] = st;        // Ut, in place: pr[] of this (I,k) triple is already in registers
       }
     }
-    __syncthreads();
+    __syncthreads();  // B3p
 
-    // ---- register-tiled contraction for the owned feature/feature blocks
+    // ---- local 3x3 transforms  Phi_ff[I] (P[I,J] Phi_ff[J]^T) (+ Qx on the diagonal), in place with 3 temporaries:
+    //      first each row times Phi_ff[J]^T, then each column times Phi_ff[I]  (keeps the register peak low)
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
-      const int I = tr + TR * ia;
-      const bool vi = own && I < N;
-      double fi[9];
-#pragma unroll
-      for (int e = 0; e < 9; e++) fi[e] = vi ? phiff[9 * I + e] : 0.0;
 #pragma unroll
       for (int ic = 0; ic < CB; ic++) {
-        const int J = tc + TC * ic;
-        const bool v = vi && J < N;
-        double fj[9], t9[9], o9[9];
+        const int tr = opaque(tr_), tc = opaque(tc_);
+        const bool own = tc < TC;
+        const int I = tr + TR * ia, J = tc + TC * ic;
+        const bool v = own && I < N && J < N;
+        const double* fj = phiff + 9 * min(J, N - 1);
 #pragma unroll
-        for (int e = 0; e < 9; e++) fj[e] = v ? phiff[9 * J + e] : 0.0;
-        mm<3, 3, 3>(fi, pb[ia][ic], t9);
+        for (int r = 0; r < 3; r++) {
+          const double p0 = pb[ia][ic][r * 3 + 0], p1 = pb[ia][ic][r * 3 + 1], p2 = pb[ia][ic][r * 3 + 2];
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+          for (int s = 0; s < 3; s++) pb[ia][ic][r * 3 + s] = p0 * fj[s * 3 + 0] + p1 * fj[s * 3 + 1] + p2 * fj[s * 3 + 2];
+        }
+        const double* fi = phiff + 9 * min(I, N - 1);
 #pragma unroll
-          for (int s = 0; s < 3; s++) o9[r * 3 + s] = t9[r * 3 + 0] * fj[s * 3 + 0] + t9[r * 3 + 1] * fj[s * 3 + 1] + t9[r * 3 + 2] * fj[s * 3 + 2];
+        for (int s = 0; s < 3; s++) {
+          const double p0 = pb[ia][ic][0 * 3 + s], p1 = pb[ia][ic][1 * 3 + s], p2 = pb[ia][ic][2 * 3 + s];
 #pragma unroll
-        for (int e = 0; e < 9; e++) pb[ia][ic][e] = o9[e];
+          for (int r = 0; r < 3; r++) pb[ia][ic][r * 3 + s] = fi[r * 3 + 0] * p0 + fi[r * 3 + 1] * p1 + fi[r * 3 + 2] * p2;
+        }
         if (v && I == J) {
           pb[ia][ic][0] += a.Qx[16 + 3 * I + 0];
           pb[ia][ic][4] += a.Qx[16 + 3 * I + 1];
           pb[ia][ic][8] += a.Qx[16 + 3 * I + 2];
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // ---- register-tiled contraction  P[I,J] += X_I Y_J^T  (K = 38)
+#pragma unroll 1
     for (int k = 0; k < XK; k += 2) {
+      const int tr = opaque(tr_), tc = opaque(tc_);
       double2 yv[CB][3];
 #pragma unroll
       for (int ic = 0; ic < CB; ic++) {
@@ -477,80 +435,60 @@ __global__ __launch_bounds__(T) void k_step_resident(StreamArgs a, int TR, int T
               acc = fma(xv[r].y, yv[ic][s].y, acc);
               pb[ia][ic][r * 3 + s] = acc;
             }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- strips and body block
-#pragma unroll
-    for (int q = 0; q < SI; q++) {   // P+[3I+r][k] = U[I][r,:] Phi_bb[k,:] + Gd_I Qu Gd_b[k]
-      const int e = tc + TC * q, ia = e >> 4, k = e & 15, I = tr + TR * ia;
-      if (own && e < RB * 16 && I < N) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const double* xr = X + (3 * I + r) * XK;
-          double s = 0.0;
-          for (int c = 0; c < 16; c++) s += xr[c] * Phibb[k * 16 + c];
-          double g = 0.0;
-          for (int c = 0; c < 6; c++) g += xr[32 + c] * Gdb[k * 6 + c];
-          sI[q][r] = s + g;
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < SJ; q++) {   // P+[k][3J+s] = Phi_bb[k,:] Ut[:,3J+s] + Gd_b[k] Qu Gd_J
-      const int e = tr + TR * q, ic = e >> 4, k = e & 15, J = tc + TC * ic;
-      if (own && e < CB * 16 && J < N) {
-#pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) {
-          double s = 0.0;
-          for (int c = 0; c < 16; c++) s += Phibb[k * 16 + c] * Pbr[c * nf + 3 * J + s3];
-          const double* xr = X + (3 * J + s3) * XK;
-          double g = 0.0;
-          for (int c = 0; c < 6; c++) g += xr[32 + c] * Gdb[k * 6 + c];
-          sJ[q][s3] = s + g;
-        }
-      }
-    }
-#pragma unroll
-    for (int w = 0; w < BBE; w++) {
-      const int e = (tid + T * w) & 255, r = e & 15, c = e >> 4;
+    // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
+#pragma unroll 1
+    for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
+      const int row = e >> 4, k = e & 15;
+      const double* xr = X + row * XK;
       double s = 0.0;
+#pragma unroll 4
+      for (int c = 0; c < 16; c++) s += xr[c] * Phibb[k * 16 + c];
+      double g = 0.0;
+#pragma unroll 2
+      for (int c = 0; c < 6; c++) g += xr[32 + c] * Gdb[k * 6 + c];
+      Pbc[e] = s + g;
+    }
+    for (int e = tid; e < 256; e += TW) {
+      const int r = e >> 4, c = e & 15;
+      double s = 0.0;
+#pragma unroll 4
       for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
       double g = 0.0;
-      for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * a.dp->Qu[k] * Gdb[c * 6 + k];
+      for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * prm.Qu[k] * Gdb[c * 6 + k];
       s = s + g;
       if (r == c) s += a.Qx[r];
-      sbb[w] = s;
+      S.Mbb[e] = s;   // P_bb+ staged in Mbb (T16 / Pbb are still being read by other threads)
     }
-    // ---- fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
-    for (int f = tid; f < len; f += T)
-#ifndef ABL_FUPD
-      res_feature_update(xs + xZ + 5 * f, false, true, 0.0, 0.0, 0.0, a.dp, &fixadd[fixpar * N + f],
-                         &fixset[fixpar * N + f], &flag, nullptr, nullptr);
-#endif
-    fixpar ^= 1;
-    __syncthreads();
+    par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
+    __syncthreads();  // B4p
+    for (int e = tid; e < 256; e += TW) Pbb[e] = S.Mbb[e];
   }
 
-  // applies the pending fix_depth covariance edits of mailbox `par` to the owned diagonal blocks
-  auto apply_fixes = [&](int par) {
+  // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks
+  auto apply_fixes = [&](int mb) {
+    if (S.sm[28 + mb] == 0.0) return;   // nothing posted (the common case): one uniform LDS read
+    const int tr = opaque(tr_), tc = opaque(tc_);
+    const bool own = tc < TC;
 #pragma unroll
     for (int ia = 0; ia < RB; ia++)
 #pragma unroll
       for (int ic = 0; ic < CB; ic++) {
         const int I = tr + TR * ia, J = tc + TC * ic;
         if (own && I == J && I < len) {
-          const double ad = fixadd[par * N + I], st = fixset[par * N + I];
-          if (ad != 0.0) { pb[ia][ic][8] += ad; fixadd[par * N + I] = 0.0; }
-          if (st != 0.0) { pb[ia][ic][8] = a.dp->P0_feat[2]; fixset[par * N + I] = 0.0; }
+          const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
+          if (ad != 0.0) { pb[ia][ic][8] += ad; S.fixadd[mb * N + I] = 0.0; }
+          if (st != 0.0) { pb[ia][ic][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
         }
       }
   };
-
-  // writes the two zeta columns of feature `slot` (raw P[:, j0], P[:, j0+1]) into Praw
+  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into Praw;
+  // the 16 body rows are read straight from Pbc by the service wave (symmetry)
   auto extract_cols = [&](int slot) {
+    const int tr = opaque(tr_), tc = opaque(tc_);
     const int cc = slot / TC, ct = slot - cc * TC;
-    if (own && tc == ct) {
+    if (tc == ct) {
 #pragma unroll
       for (int ic = 0; ic < CB; ic++)
         if (ic == cc) {
@@ -559,115 +497,40 @@ __global__ __launch_bounds__(T) void k_step_resident(StreamArgs a, int TR, int T
             const int I = tr + TR * ia;
             if (I < N)
 #pragma unroll
-              for (int r = 0; r < 3; r++) {
-                Praw[2 * (16 + 3 * I + r) + 0] = pb[ia][ic][r * 3 + 0];
-                Praw[2 * (16 + 3 * I + r) + 1] = pb[ia][ic][r * 3 + 1];
-              }
+              for (int r = 0; r < 3; r++)
+                *reinterpret_cast<double2*>(S.Praw + 2 * (16 + 3 * I + r)) = make_double2(pb[ia][ic][r * 3 + 0], pb[ia][ic][r * 3 + 1]);
           }
         }
-#pragma unroll
-      for (int q = 0; q < SJ; q++) {
-        const int e = tr + TR * q, ic = e >> 4, k = e & 15;
-        if (e < CB * 16 && ic == cc) { Praw[2 * k + 0] = sJ[q][0]; Praw[2 * k + 1] = sJ[q][1]; }
-      }
     }
   };
 
-  // =====================================================================================
-  // M sequential feature updates (vi_ekf_meas.cpp:196-278)
-  // =====================================================================================
-  const bool partial = a.dp->use_partial_update != 0;
-  // prologue: first valid measurement's columns + prediction
-  int m = 0;
-  auto meas_valid = [&](int mm_, int& slot_out) -> int {   // 0 ok, else result code
-    const int slot = slot_all[(long)b * M + mm_];
-    slot_out = slot;
-    if (slot < 0) return -1;
-    if (slot >= len) return 3;
-    const double* z = z_all + ((long)b * M + mm_) * 2;
-    if (z[0] != z[0] || z[1] != z[1]) return 2;
-    return 0;
-  };
-  auto next_valid = [&](int from) -> int {   // first m' >= from that will actually run an update; writes codes of skipped ones
-    int mm_ = from;
-    while (mm_ < M) {
-      int slot;
-      const int code = meas_valid(mm_, slot);
-      if (code == 0) break;
-      if (result_all && tid == 0) result_all[(long)b * M + mm_] = code;
-      mm_++;
-    }
-    return mm_;
-  };
-  int smp = 0;   // which half of the prediction mailbox (Hb, residual) phase A reads
-  m = next_valid(0);
-  if (m < M) {
-    const int slot = slot_all[(long)b * M + m];
-    apply_fixes(fixpar ^ 1);
-    extract_cols(slot);
-#ifndef ABL_FUPD
-    if (tid == 0)
-      res_feature_update(xs + xZ + 5 * slot, false, false, 0.0, 0.0, 0.0, a.dp, nullptr, nullptr, &flag,
-                         z_all + ((long)b * M + m) * 2, sm);
-#endif
+  // ---------------- M sequential feature updates: covariance side ----------------
+  int m = res_next_valid(S, 0);
+  if (m < S.M) {
+    apply_fixes(par ^ 1);
+    extract_cols(S.mslot[m]);
   }
-  __syncthreads();
-
-  while (m < M) {
-    const int slot = slot_all[(long)b * M + m];
-    const int j0 = 16 + 3 * slot;
-    const double* R = R_all + (long)b * r_stride_b + (long)m * r_stride_m;
-    const int mnext = next_valid(m + 1);
-    const int slot_next = (mnext < M) ? slot_all[(long)b * M + mnext] : -1;
-    // ---- phase A: S, gate, K
-    const double* smr = sm + 8 * smp;
-    double* smw = sm + 8 * (smp ^ 1);
-    const double h00 = smr[2], h01 = smr[3], h10 = smr[4], h11 = smr[5];
-    const double r0 = smr[6], r1 = smr[7];
-    double S[4], Si[4];
-    {
-      const double a0 = Praw[2 * j0 + 0], a1 = Praw[2 * j0 + 1], b0 = Praw[2 * (j0 + 1) + 0], b1 = Praw[2 * (j0 + 1) + 1];
-      // W rows j0, j0+1
-      const double w00 = a0 * h00 + a1 * h01, w01 = a0 * h10 + a1 * h11;
-      const double w10 = b0 * h00 + b1 * h01, w11 = b0 * h10 + b1 * h11;
-      S[0] = h00 * w00 + h01 * w10 + R[0];
-      S[1] = h00 * w01 + h01 * w11 + R[2];
-      S[2] = h10 * w00 + h11 * w10 + R[1];
-      S[3] = h10 * w01 + h11 * w11 + R[3];
-    }
-    inv2(S, Si);
-    const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;
-    const bool gated = mahal > 9.0;
-    int bad = 0;
-    if (!gated) {
-      for (int i = tid; i < n; i += T) {
-        const double p0 = Praw[2 * i], p1 = Praw[2 * i + 1];
-        const double w0 = p0 * h00 + p1 * h01, w1 = p0 * h10 + p1 * h11;
-        const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
-        Wt[2 * i] = w0; Wt[2 * i + 1] = w1;
-        Kt[2 * i] = k0; Kt[2 * i + 1] = k1;
-        if (k0 != k0 || k1 != k1) bad = 1;
-      }
-      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
-    }
-    bad = __syncthreads_or(bad);
-    // ---- phase B: sweep, state correction, next measurement's columns + prediction
-    apply_fixes(fixpar ^ 1);   // edits posted by the previous phase B (or by propagate)
-    if (!gated && !bad) {
-      // feature/feature blocks
+  __syncthreads();  // B1
+  while (m < S.M) {
+    const int mnext = res_next_valid(S, m + 1);
+    __syncthreads();  // B2 : gain vectors Kt / Wt and the gate verdict are in LDS
+    const double verdict = S.sm[31];   // 0 run, 1 gated, 2 NaN-guard
+    apply_fixes(par ^ 1);
+    if (verdict == 0.0) {
+      const int tr = opaque(tr_), tc = opaque(tc_);   // recompute addresses per iteration (no hoist + spill)
       double2 wJ[CB][3];
 #pragma unroll
       for (int ic = 0; ic < CB; ic++) {
         const int J = min(tc + TC * ic, N - 1);
 #pragma unroll
-        for (int s = 0; s < 3; s++) wJ[ic][s] = *reinterpret_cast<const double2*>(Wt + 2 * (16 + 3 * J + s));
+        for (int s = 0; s < 3; s++) wJ[ic][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * J + s));
       }
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
         const int I = min(tr + TR * ia, N - 1);
         double2 kI[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) kI[r] = *reinterpret_cast<const double2*>(Kt + 2 * (16 + 3 * I + r));
+        for (int r = 0; r < 3; r++) kI[r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * I + r));
 #pragma unroll
         for (int ic = 0; ic < CB; ic++)
 #pragma unroll
@@ -679,114 +542,251 @@ __global__ __launch_bounds__(T) void k_step_resident(StreamArgs a, int TR, int T
             }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // strips
+      // body columns, in LDS: item = (row, half): 8 consecutive k of one row (general Lambda_ik: body lambdas differ)
+      for (int e = opaque(tid); e < 2 * nf; e += TW) {
+        const int row = e >> 1, k0 = (e & 1) * 8;
+        const double2 ki = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + row));
+        const double li = S.lam[16 + row];
+        double* pr = Pbc + row * 16 + k0;
 #pragma unroll
-      for (int q = 0; q < SI; q++) {
-        const int e = tc + TC * q, ia = e >> 4, k = e & 15, I = tr + TR * ia;
-        if (own && e < RB * 16 && I < N) {
-          const double2 wk = *reinterpret_cast<const double2*>(Wt + 2 * k);
-          const double lk = lam[k];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            const double2 ki = *reinterpret_cast<const double2*>(Kt + 2 * (16 + 3 * I + r));
-            const double li = lam[16 + 3 * I + r];
-            const double Lm = partial ? (lk + li - li * lk) : 1.0;
-            sI[q][r] = fma(-Lm, fma(ki.y, wk.y, ki.x * wk.x), sI[q][r]);
-          }
+        for (int h = 0; h < 8; h += 2) {
+          const double2 w0 = *reinterpret_cast<const double2*>(S.Wt + 2 * (k0 + h));
+          const double2 w1 = *reinterpret_cast<const double2*>(S.Wt + 2 * (k0 + h + 1));
+          const double2 lk = *reinterpret_cast<const double2*>(S.lam + k0 + h);
+          double2 pv = *reinterpret_cast<double2*>(pr + h);
+          const double L0 = partial ? (lk.x + li - li * lk.x) : 1.0, L1 = partial ? (lk.y + li - li * lk.y) : 1.0;
+          pv.x = fma(-L0, fma(ki.y, w0.y, ki.x * w0.x), pv.x);
+          pv.y = fma(-L1, fma(ki.y, w1.y, ki.x * w1.x), pv.y);
+          *reinterpret_cast<double2*>(pr + h) = pv;
         }
       }
-#pragma unroll
-      for (int q = 0; q < SJ; q++) {
-        const int e = tr + TR * q, ic = e >> 4, k = e & 15, J = tc + TC * ic;
-        if (own && e < CB * 16 && J < N) {
-          const double2 kk = *reinterpret_cast<const double2*>(Kt + 2 * k);
-          const double lk = lam[k];
-#pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const double2 wj = *reinterpret_cast<const double2*>(Wt + 2 * (16 + 3 * J + s));
-            const double lj = lam[16 + 3 * J + s];
-            const double Lm = partial ? (lj + lk - lk * lj) : 1.0;
-            sJ[q][s] = fma(-Lm, fma(kk.y, wj.y, kk.x * wj.x), sJ[q][s]);
-          }
-        }
-      }
-#pragma unroll
-      for (int w = 0; w < BBE; w++) {
-        const int e = (tid + T * w) & 255, r = e & 15, c = e >> 4;
-        const double2 kr = *reinterpret_cast<const double2*>(Kt + 2 * r);
-        const double2 wc = *reinterpret_cast<const double2*>(Wt + 2 * c);
-        const double lr = lam[r], lc = lam[c];
+      for (int e = opaque(tid); e < 256; e += TW) {   // body block
+        const int r = e >> 4, c = e & 15;
+        const double2 kr = *reinterpret_cast<const double2*>(S.Kt + 2 * r);
+        const double2 wc = *reinterpret_cast<const double2*>(S.Wt + 2 * c);
+        const double lr = S.lam[r], lc = S.lam[c];
         const double Lm = partial ? (lc + lr - lr * lc) : 1.0;
-        sbb[w] = fma(-Lm, fma(kr.y, wc.y, kr.x * wc.x), sbb[w]);
+        Pbb[e] = fma(-Lm, fma(kr.y, wc.y, kr.x * wc.x), Pbb[e]);
       }
-      // state correction x <- x [+] (lambda o K r)  (vi_ekf_meas.cpp:254-255 / :262-263)
-#ifndef ABL_BUPD
-      if (tid == T - 1) res_body_update(xs, Kt, lam, partial, r0, r1);
-#endif
     }
-    for (int f = tid; f < len; f += T) {
-      double* xf = xs + xZ + 5 * f;
-      const int d = 16 + 3 * f;
-      double dv[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const double l = partial ? lam[d + q] : 1.0;
-        dv[q] = (l * Kt[2 * (d + q)]) * r0 + (l * Kt[2 * (d + q) + 1]) * r1;
-      }
-#ifndef ABL_FUPD
-      res_feature_update(xf, !gated && !bad, !gated, dv[0], dv[1], dv[2], a.dp, &fixadd[fixpar * N + f],
-                         &fixset[fixpar * N + f], &flag,
-                         (f == slot_next) ? (z_all + ((long)b * M + mnext) * 2) : nullptr, smw);
-#endif
-    }
-    if (result_all && tid == 0) result_all[(long)b * M + m] = gated ? 1 : 0;
-    fixpar ^= 1;
-    smp ^= 1;
-    if (slot_next >= 0) extract_cols(slot_next);   // reads the swept registers
+    par ^= 1;
+    if (mnext < S.M) extract_cols(S.mslot[mnext]);   // reads the swept registers
     // NOTE: a fix_depth edit touches P(rho,rho) only, never the zeta columns just extracted
-    __syncthreads();
+    __syncthreads();  // B1
     m = mnext;
   }
-  apply_fixes(fixpar ^ 1);
+  apply_fixes(par ^ 1);
+  __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
 
   // ---------------- store ----------------
-  for (int i = tid; i < xZ + 5 * len; i += T) {
+  // (indices re-derived from opaque copies: otherwise the load addresses are kept alive -- spilled -- all kernel long)
+  {
+    const int tr = opaque(tr_), tc = opaque(tc_);
+    const bool own = tc < TC;
+    const int toff = 3 * tr + 3 * tc * ld;
+#pragma unroll
+    for (int ia = 0; ia < RB; ia++)
+#pragma unroll
+      for (int ic = 0; ic < CB; ic++) {
+        const int I = tr + TR * ia, J = tc + TC * ic;
+        if (own && I < N && J < N)
+#pragma unroll
+          for (int s = 0; s < 3; s++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+              double* pu = P + ((16 + r + 3 * TR * ia) + (long)(16 + s + 3 * TC * ic) * ld);
+              pu[toff] = pb[ia][ic][r * 3 + s];
+            }
+      }
+    for (int e = opaque(tid); e < nf * 16; e += TW) {     // body columns, coalesced along rows
+      const int k = e / nf, row = e - k * nf;
+      P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];
+    }
+    for (int e = opaque(tid); e < nf * 16; e += TW) {     // mirrored body rows, coalesced along k
+      const int row = e >> 4, k = e & 15;
+      P[k + (long)(16 + row) * ld] = Pbc[e];
+    }
+    for (int e = opaque(tid); e < 256; e += TW) P[(e >> 4) + (long)(e & 15) * ld] = Pbb[e];
+  }
+}
+
+// ---- the service wave: everything that is not a sweep over P --------------------------------------
+__device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane,
+                                            const double* __restrict__ u_all, int* __restrict__ result_all) {
+  const int N = S.N, n = S.n, len = S.len, M = S.M;
+  const DevParams& prm = *a.dp;
+  double* xs = S.xs;
+  double* sm = S.sm;
+  unsigned flag = 0;
+  const bool partial = prm.use_partial_update != 0;
+  int par = 0;
+  __syncthreads();  // B0
+
+  if (S.do_prop) {
+    const double dt = sm[30];
+    if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
+    __syncthreads();  // B1p
+    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, a.dp, S.Abb, S.Gb, S.X, S.Y, S.phiff);
+    __syncthreads();  // B2p
+    if (lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
+      double dxb[16], xo[17];
+#pragma unroll
+      for (int i = 0; i < 16; i++) dxb[i] = S.xdb[i] * dt;
+      body_boxplus_fast(xs, dxb, xo);
+#pragma unroll
+      for (int i = 0; i < 17; i++) xs[i] = xo[i];
+    }
+    if (lane == 0) sm[28 + par] = 0.0;
+    for (int f = lane; f < len; f += 64)   // fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
+      res_feature_update(xs + xZ + 5 * f, false, true, 0.0, 0.0, 0.0, a.dp, &S.fixadd[par * N + f],
+                         &S.fixset[par * N + f], &sm[28 + par], &flag, nullptr, nullptr);
+    par ^= 1;
+    __syncthreads();  // B3p
+    __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
+  }
+
+  int smp = 0;   // which half of the prediction mailbox (Hb, residual) the gain step reads
+  int m = res_next_valid(S, 0);
+  if (m < M) {
+    const int slot = S.mslot[m];
+    if (lane == 0)
+      res_feature_update(xs + xZ + 5 * slot, false, false, 0.0, 0.0, 0.0, a.dp, nullptr, nullptr, nullptr, &flag,
+                         S.mz + 2 * m, sm);
+  }
+  __syncthreads();  // B1
+
+  const int nb = 64 - N;   // lanes N..63 share the 16 body rows
+  while (m < M) {
+    const int slot = S.mslot[m];
+    const int j0 = 16 + 3 * slot;
+    const double* R = S.mR + 4 * m;
+    const int mnext = res_next_valid(S, m + 1);
+    const int slot_next = (mnext < M) ? S.mslot[mnext] : -1;
+    // ---- innovation covariance, gate, gain rows (vi_ekf_meas.cpp:232-247)
+    const double* smr = sm + 8 * smp;
+    double* smw = sm + 8 * (smp ^ 1);
+    const double h00 = smr[2], h01 = smr[3], h10 = smr[4], h11 = smr[5];
+    const double r0 = smr[6], r1 = smr[7];
+    double Sm[4], Si[4];
+    {
+      const double a0 = S.Praw[2 * j0 + 0], a1 = S.Praw[2 * j0 + 1], b0 = S.Praw[2 * (j0 + 1) + 0], b1 = S.Praw[2 * (j0 + 1) + 1];
+      const double w00 = a0 * h00 + a1 * h01, w01 = a0 * h10 + a1 * h11;
+      const double w10 = b0 * h00 + b1 * h01, w11 = b0 * h10 + b1 * h11;
+      Sm[0] = h00 * w00 + h01 * w10 + R[0];
+      Sm[1] = h00 * w01 + h01 * w11 + R[2];
+      Sm[2] = h10 * w00 + h11 * w10 + R[1];
+      Sm[3] = h10 * w01 + h11 * w11 + R[3];
+    }
+    inv2(Sm, Si);
+    const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;
+    const bool gated = mahal > 9.0;
+    double dv[3] = {0.0, 0.0, 0.0};   // lambda o (K r) of this lane's feature rows
+    int bad = 0;
+    if (!gated) {
+      auto row = [&](int i, double& dxi) {
+        // feature rows come from the extracted columns; body rows from the LDS-resident body columns (symmetry)
+        const double2 pr = (i >= 16) ? *reinterpret_cast<const double2*>(S.Praw + 2 * i)
+                                     : make_double2(S.Pbc[(3 * slot + 0) * 16 + i], S.Pbc[(3 * slot + 1) * 16 + i]);
+        const double w0 = pr.x * h00 + pr.y * h01, w1 = pr.x * h10 + pr.y * h11;
+        const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
+        *reinterpret_cast<double2*>(S.Wt + 2 * i) = make_double2(w0, w1);
+        *reinterpret_cast<double2*>(S.Kt + 2 * i) = make_double2(k0, k1);
+        if (k0 != k0 || k1 != k1) bad = 1;
+        const double l = partial ? S.lam[i] : 1.0;
+        dxi = (l * k0) * r0 + (l * k1) * r1;
+      };
+      if (lane < N) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) row(16 + 3 * lane + q, dv[q]);
+      } else {
+        for (int i = lane - N; i < 16; i += nb) { double d; row(i, d); S.sm[32 + i] = d; }   // body dx -> LDS
+      }
+      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
+      bad = __any(bad);
+    }
+    if (lane == 0) sm[31] = gated ? 1.0 : (bad ? 2.0 : 0.0);
+    __syncthreads();  // B2
+    // ---- state correction x <- x [+] (lambda o K r), fix_depth, next prediction
+    const bool corr = !gated && !bad;
+    if (corr && lane == 63) {   // body (vi_ekf_helper.cpp:90-92)
+      double dxb[16], xo[17];
+#pragma unroll
+      for (int i = 0; i < 16; i++) dxb[i] = S.sm[32 + i];
+      body_boxplus_fast(xs, dxb, xo);
+#pragma unroll
+      for (int i = 0; i < 17; i++) xs[i] = xo[i];
+    }
+    if (lane == 0) sm[28 + par] = 0.0;
+    if (lane < len)
+      res_feature_update(xs + xZ + 5 * lane, corr, !gated, dv[0], dv[1], dv[2], a.dp, &S.fixadd[par * N + lane],
+                         &S.fixset[par * N + lane], &sm[28 + par], &flag,
+                         (lane == slot_next) ? (S.mz + 2 * mnext) : nullptr, smw);
+    if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
+    par ^= 1;
+    smp ^= 1;
+    __syncthreads();  // B1
+    m = mnext;
+  }
+
+  __syncthreads();  // B5
+  // ---------------- store x, status ----------------
+  double* xg = a.x + (long)S.b * a.nxs;
+  for (int i = lane; i < xZ + 5 * len; i += 64) {
     const double v = xs[i];
     if (v != v) flag |= FLAG_NAN;
     if (v > 1e6) flag |= FLAG_BLOWUP;
     xg[i] = v;
   }
-#pragma unroll
-  for (int ia = 0; ia < RB; ia++)
-#pragma unroll
-    for (int ic = 0; ic < CB; ic++) {
-      const int I = tr + TR * ia, J = tc + TC * ic;
-      if (own && I < N && J < N)
-#pragma unroll
-        for (int s = 0; s < 3; s++)
-#pragma unroll
-          for (int r = 0; r < 3; r++) P[(16 + 3 * I + r) + (long)(16 + 3 * J + s) * ld] = pb[ia][ic][r * 3 + s];
+  if (flag) atomicOr(&a.flags[S.b], flag);
+}
+
+template <int RB, int CB, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, int TR, int TC, int do_prop,
+                                                                const double* __restrict__ u_all,
+                                                                const double* __restrict__ dt_all,
+                                                                const double* __restrict__ z_all,
+                                                                const int* __restrict__ slot_all, int M, int m_stride,
+                                                                const double* __restrict__ R_all, long r_stride_b,
+                                                                long r_stride_m, int* __restrict__ result_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int T = (NW + 1) * 64, TW = NW * 64;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const ResLds L(a.N, a.n, a.nxs);
+  ResShared S;
+  S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
+  S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.X = smem + L.X; S.Y = smem + L.Y;
+  S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
+  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc;
+  S.mz = smem + L.mz; S.mR = smem + L.mR;
+  S.mslot = reinterpret_cast<int*>(smem + L.mslot);
+  S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
+  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop; S.b = b;
+
+  // ---- common prologue: state, lambdas, mailboxes, measurement table (validity decided once, here)
+  {
+    const double* xg = a.x + (long)b * a.nxs;
+    for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
+    for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
+    for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
+    if (tid == 0) { S.sm[30] = do_prop ? dt_all[b] : 0.0; S.sm[28] = 0.0; S.sm[29] = 0.0; }
+    for (int mm_ = tid; mm_ < M; mm_ += T) {
+      const int slot = slot_all[(long)b * m_stride + mm_];
+      const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];
+      int code = 0;
+      if (slot < 0) code = -1;                       // skipped
+      else if (slot >= S.len) code = 3;              // MEAS_INVALID
+      else if (z0 != z0 || z1 != z1) code = 2;       // MEAS_NAN (vi_ekf_meas.cpp:136-137)
+      S.mslot[mm_] = (code == 0) ? slot : -1;
+      S.mz[2 * mm_] = z0; S.mz[2 * mm_ + 1] = z1;
+      const double* R = R_all + (long)b * r_stride_b + (long)mm_ * r_stride_m;
+      S.mR[4 * mm_ + 0] = R[0]; S.mR[4 * mm_ + 1] = R[1]; S.mR[4 * mm_ + 2] = R[2]; S.mR[4 * mm_ + 3] = R[3];
+      if (code != 0 && result_all) result_all[(long)b * m_stride + mm_] = code;
     }
-#pragma unroll
-  for (int q = 0; q < SI; q++) {
-    const int e = tc + TC * q, ia = e >> 4, k = e & 15, I = tr + TR * ia;
-    if (own && e < RB * 16 && I < N)
-#pragma unroll
-      for (int r = 0; r < 3; r++) P[(16 + 3 * I + r) + (long)k * ld] = sI[q][r];
   }
-#pragma unroll
-  for (int q = 0; q < SJ; q++) {
-    const int e = tr + TR * q, ic = e >> 4, k = e & 15, J = tc + TC * ic;
-    if (own && e < CB * 16 && J < N)
-#pragma unroll
-      for (int s = 0; s < 3; s++) P[k + (long)(16 + 3 * J + s) * ld] = sJ[q][s];
-  }
-#pragma unroll
-  for (int w = 0; w < BBE; w++) {
-    const int e = tid + T * w;
-    if (e < 256) P[(e & 15) + (long)(e >> 4) * ld] = sbb[w];
-  }
-  if (flag) atomicOr(&a.flags[b], flag);
+  __syncthreads();
+  if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
+  else res_worker<RB, CB, TW>(a, S, TR, TC, tid);
 }
 
 }  // namespace viekf
