@@ -188,6 +188,18 @@ def main():
     alg_bytes = scene.algorithmic_bytes_per_step(N) * B  # one launch processes B filter-steps
     achieved = alg_bytes / launch_s / 1e9
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
+    # profiler on itself): FETCH_SIZE (x2, gfx950 rule) + WRITE_SIZE, see profiles/<round>/*_pmc_traffic.json
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_traffic.json"))):
+            j = json.load(open(f))
+            if j["config"]["batch"] == B and j["config"]["n_feat"] == N and args.kernel in (0, 2):
+                traffic, traffic_src = j["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+    except Exception:
+        traffic = None
+
     if rank == 0:
         total_filters = B * world
         out = {
@@ -208,8 +220,9 @@ def main():
                        "batch_per_gpu": B, "n_feat": N, "parallelism": "filters sharded %d-way, no collective" % world,
                        "kernel_family": args.kernel},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step launch group (propagate + update), median HIP-event duration %.4f ms" % (launch_s * 1e3),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_step_resident (one fused launch per step: propagate + %d updates, P resident in "
+                                   "VGPRs/LDS), median HIP-event duration %.4f ms" % (N, launch_s * 1e3),
                          "alg_bytes_per_launch": alg_bytes},
             "nan_filters": n_bad,
         }

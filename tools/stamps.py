@@ -1,0 +1,42 @@
+"""Diagnostic: runs ONE step with a -DVIEKF_STAMPS build (VIEKF_LIB=...) and prints the s_memtime deltas of block 0."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa
+
+import vi_ekf_amd as v
+from vi_ekf_amd import scene, capi
+
+B, N = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 50
+sc = scene.make_scene(B, N, 2, seed=3)
+g = v.BatchVIEKF(B, N, sc["params"])
+for i in range(N):
+    g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+for rep in range(2):
+    g.step(sc["u"][rep], sc["dt"], sc["z"][rep], sc["slot"], sc["R"])
+# read the workspace of block 0 through a debug hook: the stamps live at d_ws[0..127]
+ws = np.zeros(192, dtype=np.uint64)
+capi.lib().viekf_debug_read_ws.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+capi.check(capi.lib().viekf_debug_read_ws(g._h, C.c_void_p(ws.ctypes.data), 192))
+t = ws.astype(np.int64)
+def d(a, b): return int(t[b] - t[a])
+print("common prologue (62->63 incl barrier)", d(62, 63))
+print("service: B0 wait", d(0, 1), " body phase", d(1, 2), " B1p wait", d(2, 3), " feature phase", d(3, 4), " B2p wait", d(4, 5),
+      " body step+fix", d(5, 6), " B3p wait", d(6, 7), " B4p wait (GEMM)", d(7, 8), " first h_feat", d(8, 9), " B1 wait", d(9, 10))
+print("worker : load->B0", d(63, 64), " B0 wait", d(64, 65), " to B3p", d(65, 66), " B3p wait", d(66, 67), " local3x3", d(67, 68),
+      " GEMM", d(68, 69), " strips", d(69, 70), " B4p+extract->B1", d(70, 71))
+for it in range(8):
+    s0 = 16 + 4 * it; w0 = 80 + 4 * it
+    print("update %d  service: gain %5d | B2 wait %5d | correct+h %5d | B1 wait %5d     worker: B2 wait %5d | sweep %5d | extract %5d | B1 wait(next) " % (
+        it, d(s0 - 1 if it else 10, s0), d(s0, s0 + 1), d(s0 + 1, s0 + 2), d(s0 + 2, s0 + 3), d(w0, w0 + 1), d(w0 + 1, w0 + 2), d(w0 + 2, w0 + 3)))
+for it in range(4):
+    s0 = 16 + 4 * it; q0 = 128 + 4 * it
+    print("update %d service detail: rows+dv %5d | boxplus %5d | fix+h_feat %5d" % (it, d(s0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, s0 + 2)))
+for it in range(4):
+    w0 = 80 + 4 * it; q0 = 160 + 4 * it
+    print("update %d worker detail: blocks %5d | body cols %5d | body block %5d" % (it, d(w0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, w0 + 2)))
+print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(63, 73))

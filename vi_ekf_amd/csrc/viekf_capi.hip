@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -166,6 +167,13 @@ int setup_resident(viekf_batch* b) {
   return VIEKF_OK;
 }
 
+// VIEKF_DEBUG_ABLATE: timing-only switches (results become wrong): 1 skip sweeps, 2 skip state correction, 4 skip gain rows
+int dbg_bits() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VIEKF_DEBUG_ABLATE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family != 1; }
 
 // one launch handles at most MCAP measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
@@ -180,7 +188,7 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   do {
     const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
     hipLaunchKernelGGL(res_kernel(b->res_inst), dim3(b->B), dim3((r.NW + 1) * 64), b->res_lds, b->stream, a, b->res_TR,
-                       b->res_TC, (do_prop && m0 == 0) ? 1 : 0, d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
+                       b->res_TC, ((do_prop && m0 == 0) ? 1 : 0) | (dbg_bits() << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
     HIP_TRY(hipGetLastError());
@@ -539,6 +547,15 @@ static int update_or_step(viekf_batch* b, const double* u, const double* dt, boo
     if (result && M > 0) HIP_TRY(hipMemcpyAsync(result, d_res, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
   }
+  return VIEKF_OK;
+}
+
+// diagnostic hook (not part of include/viekf.h): first `count` 8-byte words of the device workspace
+int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->d_ws, (size_t)count * 8, hipMemcpyDeviceToHost));
   return VIEKF_OK;
 }
 

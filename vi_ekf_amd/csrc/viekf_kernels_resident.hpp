@@ -31,7 +31,7 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
-    Kt = take(2 * n); Wt = take(2 * n); Praw = take(2 * n); lam = take(n);
+    Kt = take(2 * n); Wt = take(2 * n); Praw = take(4 * n); lam = take(n);   // Praw: two buffers of [n][2]
     sm = take(48);   // [0..15] two prediction mailboxes, [28..29] fix mailboxes non-empty, [30] dt, [31] gate verdict, [32..47] body dx
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
     X = take(nf * XK); Y = take(nf * XK);
@@ -77,9 +77,48 @@ __device__ __forceinline__ void q_exp_fast(const double* v, double* o) {
   }
 }
 
+// [t1 t2 zeta] = columns of R(q)^T = rota(e_x), rota(e_y), rota(e_z) written out (the same polynomial in q as
+// src/quat.cpp:279-283 applied to the unit vectors, ~30 flops instead of three generic rotations)
+__device__ __forceinline__ void bearing_frame_fast(const double* q, double* t1, double* t2, double* z) {
+  const double w = q[0], x = q[1], y = q[2], zz_ = q[3];
+  const double xx = x * x, yy = y * y, zz = zz_ * zz_, xy = x * y, xz = x * zz_, yz = y * zz_, wx = w * x, wy = w * y,
+               wz = w * zz_;
+  t1[0] = 1.0 - 2.0 * (yy + zz); t1[1] = 2.0 * (xy + wz);       t1[2] = 2.0 * (xz - wy);
+  t2[0] = 2.0 * (xy - wz);       t2[1] = 1.0 - 2.0 * (xx + zz); t2[2] = 2.0 * (yz + wx);
+  z[0] = 2.0 * (xz + wy);        z[1] = 2.0 * (yz - wx);        z[2] = 1.0 - 2.0 * (xx + yy);
+}
+
+// h_feat (vi_ekf_meas.cpp:354-367) with the matrix chain multiplied out.  [zeta]x T_z = [zeta x t1, zeta x t2]
+// (= [t2, -t1] for a unit q_zeta; the cross products are kept so a non-unit q behaves like the reference), and
+// F ((zeta e_z^T)/ez - I) w = (f0 (zeta_x w_z/ez - w_x), f1 (zeta_y w_z/ez - w_y)).  One reciprocal.
+__device__ __forceinline__ void h_feat_fast(const double* qz, const DevParams& p, double* zhat, double* Hb) {
+  double t1[3], t2[3], z[3];
+  bearing_frame_fast(qz, t1, t2, z);
+  const double iez = 1.0 / z[2];
+  const double zx = z[0] * iez, zy = z[1] * iez;
+  zhat[0] = p.focal[0] * zx + p.cam_center[0];
+  zhat[1] = p.focal[1] * zy + p.cam_center[1];
+  double c1[3], c2[3];
+  cross3(z, t1, c1);
+  cross3(z, t2, c2);
+  const double f0 = p.focal[0] * iez, f1 = p.focal[1] * iez;
+  Hb[0] = f0 * (zx * c1[2] - c1[0]);
+  Hb[1] = f0 * (zx * c2[2] - c2[0]);
+  Hb[2] = f1 * (zy * c1[2] - c1[1]);
+  Hb[3] = f1 * (zy * c2[2] - c2[1]);
+}
+
+// 2x2 inverse through the adjugate and ONE reciprocal (the reference's LU form, vi_ekf_meas.cpp:232, differs by
+// rounding only; three dependent fp64 divisions would sit on the per-update critical path)
+__device__ __forceinline__ void inv2_fast(const double* S, double* Si) {
+  const double det = S[0] * S[3] - S[1] * S[2];
+  const double r = 1.0 / det;
+  Si[0] = S[3] * r; Si[1] = -S[1] * r; Si[2] = -S[2] * r; Si[3] = S[0] * r;
+}
+
 __device__ __forceinline__ void q_feat_boxplus_fast(const double* q, double d0, double d1, double* o) {
   double t1[3], t2[3], z[3], v[3], e[4];
-  bearing_frame(q, t1, t2, z);
+  bearing_frame_fast(q, t1, t2, z);
   v[0] = t1[0] * d0 + t2[0] * d1;
   v[1] = t1[1] * d0 + t2[1] * d1;
   v[2] = t1[2] * d0 + t2[2] * d1;
@@ -217,7 +256,7 @@ __device__ RES_INLINE void res_feature_update(double* xf, bool do_corr, bool do_
   }
   if (z_next) {
     double zhat[2], Hb[4];
-    h_feat(xf, *p, zhat, Hb);
+    h_feat_fast(xf, *p, zhat, Hb);
     smw[2] = Hb[0]; smw[3] = Hb[1]; smw[4] = Hb[2]; smw[5] = Hb[3];
     smw[6] = z_next[0] - zhat[0]; smw[7] = z_next[1] - zhat[1];
   }
@@ -252,6 +291,20 @@ __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-unif
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// Diagnostic build only (-DVIEKF_STAMPS): s_memtime stamps of block 0 into the (otherwise unused) workspace.
+#ifdef VIEKF_STAMPS
+#define RES_STAMP(S_, who, idx)                                                                  \
+  do {                                                                                           \
+    if ((S_).b == 0 && (who)) {                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      reinterpret_cast<unsigned long long*>((S_).stamps)[(idx)] = __builtin_amdgcn_s_memtime();  \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  } while (0)
+#else
+#define RES_STAMP(S_, who, idx) do {} while (0)
+#endif
+
 constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lists)
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
@@ -259,7 +312,8 @@ struct ResShared {  // resolved LDS pointers + launch constants shared by both r
       *xdb, *Pbc, *mz, *mR;
   int* mslot;   // [MCAP] slot, or -(code+2) for a measurement that is not run (code -1/2/3 -> -1/-4/-5)
   BodyCtx* ctx;
-  int N, n, nf, len, M, mstride, do_prop, b;
+  int N, n, nf, len, M, mstride, do_prop, b, dbg;
+  double* stamps;
 };
 
 // first m' >= from whose update will actually run (mslot >= 0), else M
@@ -320,7 +374,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   }
   const bool partial = prm.use_partial_update != 0;
   int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  RES_STAMP(S, tid == 0, 64);
   __syncthreads();  // B0
+  RES_STAMP(S, tid == 0, 65);
 
   if (S.do_prop) {
     double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
@@ -373,7 +429,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         Y[(3 * I + r) * XK + 16 + k] = sv;   // V
       }
     }
+    RES_STAMP(S, tid == 0, 66);
     __syncthreads();  // B3p
+    RES_STAMP(S, tid == 0, 67);
 
     // ---- local 3x3 transforms  Phi_ff[I] (P[I,J] Phi_ff[J]^T) (+ Qx on the diagonal), in place with 3 temporaries:
     //      first each row times Phi_ff[J]^T, then each column times Phi_ff[I]  (keeps the register peak low)
@@ -407,6 +465,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    RES_STAMP(S, tid == 0, 68);
     // ---- register-tiled contraction  P[I,J] += X_I Y_J^T  (K = 38)
 #pragma unroll 1
     for (int k = 0; k < XK; k += 2) {
@@ -437,6 +496,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
             }
       }
     }
+    RES_STAMP(S, tid == 0, 69);
     // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
 #pragma unroll 1
     for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
@@ -462,6 +522,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       S.Mbb[e] = s;   // P_bb+ staged in Mbb (T16 / Pbb are still being read by other threads)
     }
     par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
+    RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
     for (int e = tid; e < 256; e += TW) Pbb[e] = S.Mbb[e];
   }
@@ -483,11 +544,12 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         }
       }
   };
-  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into Praw;
-  // the 16 body rows are read straight from Pbc by the service wave (symmetry)
-  auto extract_cols = [&](int slot) {
+  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into the
+  // Praw buffer `buf`
+  auto extract_cols = [&](int slot, int buf) {
     const int tr = opaque(tr_), tc = opaque(tc_);
     const int cc = slot / TC, ct = slot - cc * TC;
+    double* Pw = S.Praw + buf * 2 * n;
     if (tc == ct) {
 #pragma unroll
       for (int ic = 0; ic < CB; ic++)
@@ -498,25 +560,57 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
             if (I < N)
 #pragma unroll
               for (int r = 0; r < 3; r++)
-                *reinterpret_cast<double2*>(S.Praw + 2 * (16 + 3 * I + r)) = make_double2(pb[ia][ic][r * 3 + 0], pb[ia][ic][r * 3 + 1]);
+                *reinterpret_cast<double2*>(Pw + 2 * (16 + 3 * I + r)) = make_double2(pb[ia][ic][r * 3 + 0], pb[ia][ic][r * 3 + 1]);
           }
         }
     }
   };
+  // body rows of those columns = rows 3 slot, 3 slot + 1 of the LDS-resident body columns (symmetry)
+  auto extract_body = [&](int slot, int buf) {
+    double* Pw = S.Praw + buf * 2 * n;
+    const int e = opaque(tid);
+    if (e < 32) Pw[2 * (e & 15) + (e >> 4)] = Pbc[(3 * slot + (e >> 4)) * 16 + (e & 15)];
+  };
 
   // ---------------- M sequential feature updates: covariance side ----------------
+  int smp = 0, pp = 0;
   int m = res_next_valid(S, 0);
   if (m < S.M) {
     apply_fixes(par ^ 1);
-    extract_cols(S.mslot[m]);
+    extract_cols(S.mslot[m], 0);
+    extract_body(S.mslot[m], 0);
   }
+  RES_STAMP(S, tid == 0, 71);
   __syncthreads();  // B1
+  int it_ = 0;
   while (m < S.M) {
     const int mnext = res_next_valid(S, m + 1);
-    __syncthreads();  // B2 : gain vectors Kt / Wt and the gate verdict are in LDS
-    const double verdict = S.sm[31];   // 0 run, 1 gated, 2 NaN-guard
+    const int slot_next = (mnext < S.M) ? S.mslot[mnext] : -1;
+    // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T needs only the prediction -> before B2a;  K_i = W_i S^-1 after it
+    const int irow = min(opaque(tid), n - 1);
+    double w0, w1;
+    bool hnan;
+    {
+      const double* smr = S.sm + 8 * smp;
+      const double2 hA = *reinterpret_cast<const double2*>(smr + 2), hB = *reinterpret_cast<const double2*>(smr + 4);
+      const double2 pr = *reinterpret_cast<const double2*>(S.Praw + pp * 2 * n + 2 * irow);
+      w0 = pr.x * hA.x + pr.y * hA.y; w1 = pr.x * hB.x + pr.y * hB.y;
+      hnan = hA.x != hA.x || hA.y != hA.y || hB.x != hB.x || hB.y != hB.y;
+      if (tid < n) *reinterpret_cast<double2*>(S.Wt + 2 * irow) = make_double2(w0, w1);
+    }
+    RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 0);
+    __syncthreads();  // B2a : S^-1 and the gate verdict are in LDS
+    if (tid < n) {   // (vi_ekf_meas.cpp:241)
+      const double2 sA = *reinterpret_cast<const double2*>(S.sm + 20), sB = *reinterpret_cast<const double2*>(S.sm + 22);
+      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
+      *reinterpret_cast<double2*>(S.Kt + 2 * irow) = make_double2(k0, k1);
+      if (k0 != k0 || k1 != k1 || hnan) S.sm[27] = 1.0;
+    }
+    __syncthreads();  // B2b : gain vectors Kt / Wt are in LDS
+    RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
+    const bool run = S.sm[31] == 0.0 && S.sm[27] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     apply_fixes(par ^ 1);
-    if (verdict == 0.0) {
+    if (run) {
       const int tr = opaque(tr_), tc = opaque(tc_);   // recompute addresses per iteration (no hoist + spill)
       double2 wJ[CB][3];
 #pragma unroll
@@ -542,12 +636,17 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
             }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // body columns, in LDS: item = (row, half): 8 consecutive k of one row (general Lambda_ik: body lambdas differ)
+      RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
+      // body columns, in LDS: item = (row, half): 8 consecutive k of one row (general Lambda_ik: body lambdas differ).
+      // The two rows that are the next measurement's columns are published into the other Praw buffer on the fly.
+      double* Pn = S.Praw + (pp ^ 1) * 2 * n;
       for (int e = opaque(tid); e < 2 * nf; e += TW) {
         const int row = e >> 1, k0 = (e & 1) * 8;
         const double2 ki = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + row));
         const double li = S.lam[16 + row];
         double* pr = Pbc + row * 16 + k0;
+        const int cn = row - 3 * slot_next;   // 0 / 1 -> this row is column cn of the next measurement
+        const bool pub = slot_next >= 0 && (cn == 0 || cn == 1);
 #pragma unroll
         for (int h = 0; h < 8; h += 2) {
           const double2 w0 = *reinterpret_cast<const double2*>(S.Wt + 2 * (k0 + h));
@@ -558,8 +657,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
           pv.x = fma(-L0, fma(ki.y, w0.y, ki.x * w0.x), pv.x);
           pv.y = fma(-L1, fma(ki.y, w1.y, ki.x * w1.x), pv.y);
           *reinterpret_cast<double2*>(pr + h) = pv;
+          if (pub) { Pn[2 * (k0 + h) + cn] = pv.x; Pn[2 * (k0 + h + 1) + cn] = pv.y; }
         }
       }
+      RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
       for (int e = opaque(tid); e < 256; e += TW) {   // body block
         const int r = e >> 4, c = e & 15;
         const double2 kr = *reinterpret_cast<const double2*>(S.Kt + 2 * r);
@@ -568,14 +669,22 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         const double Lm = partial ? (lc + lr - lr * lc) : 1.0;
         Pbb[e] = fma(-Lm, fma(kr.y, wc.y, kr.x * wc.x), Pbb[e]);
       }
+    } else if (slot_next >= 0) {
+      extract_body(slot_next, pp ^ 1);   // nothing was swept: the body columns are unchanged
     }
     par ^= 1;
-    if (mnext < S.M) extract_cols(S.mslot[mnext]);   // reads the swept registers
+    RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 2);
+    if (slot_next >= 0) extract_cols(slot_next, pp ^ 1);   // reads the swept registers
     // NOTE: a fix_depth edit touches P(rho,rho) only, never the zeta columns just extracted
+    pp ^= 1;
+    smp ^= 1;
+    RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 3);
     __syncthreads();  // B1
+    it_++;
     m = mnext;
   }
   apply_fixes(par ^ 1);
+  RES_STAMP(S, tid == 0, 72);
   __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
 
   // ---------------- store ----------------
@@ -608,6 +717,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     for (int e = opaque(tid); e < 256; e += TW) P[(e >> 4) + (long)(e & 15) * ld] = Pbb[e];
   }
+  RES_STAMP(S, tid == 0, 73);
 }
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
@@ -620,14 +730,20 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   unsigned flag = 0;
   const bool partial = prm.use_partial_update != 0;
   int par = 0;
+  RES_STAMP(S, lane == 0, 0);
   __syncthreads();  // B0
+  RES_STAMP(S, lane == 0, 1);
 
   if (S.do_prop) {
     const double dt = sm[30];
     if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
+    RES_STAMP(S, lane == 0, 2);
     __syncthreads();  // B1p
+    RES_STAMP(S, lane == 0, 3);
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, a.dp, S.Abb, S.Gb, S.X, S.Y, S.phiff);
+    RES_STAMP(S, lane == 0, 4);
     __syncthreads();  // B2p
+    RES_STAMP(S, lane == 0, 5);
     if (lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
       double dxb[16], xo[17];
 #pragma unroll
@@ -641,11 +757,15 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       res_feature_update(xs + xZ + 5 * f, false, true, 0.0, 0.0, 0.0, a.dp, &S.fixadd[par * N + f],
                          &S.fixset[par * N + f], &sm[28 + par], &flag, nullptr, nullptr);
     par ^= 1;
+    RES_STAMP(S, lane == 0, 6);
     __syncthreads();  // B3p
+    RES_STAMP(S, lane == 0, 7);
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
+    RES_STAMP(S, lane == 0, 8);
   }
 
   int smp = 0;   // which half of the prediction mailbox (Hb, residual) the gain step reads
+  int pp = 0;    // which Praw buffer holds the current measurement's columns
   int m = res_next_valid(S, 0);
   if (m < M) {
     const int slot = S.mslot[m];
@@ -653,82 +773,144 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       res_feature_update(xs + xZ + 5 * slot, false, false, 0.0, 0.0, 0.0, a.dp, nullptr, nullptr, nullptr, &flag,
                          S.mz + 2 * m, sm);
   }
+  RES_STAMP(S, lane == 0, 9);
   __syncthreads();  // B1
+  RES_STAMP(S, lane == 0, 10);
+  int it_ = 0;
 
-  const int nb = 64 - N;   // lanes N..63 share the 16 body rows
+  // lane roles for the state correction (one instruction stream, no divergence):
+  //   lane f < N           : feature f  -> rows 16+3f..+2 : bearing quaternion (2 rows) + inverse depth (1 row)
+  //   lane N+j, j = 0..5   : body row j            (p, v)          linear state x[j]
+  //   lane N+6             : body rows 6,7,8       (attitude)      quaternion x[6..9], right-multiplied
+  //   lane N+j, j = 7..13  : body row j+2 = 9..15  (b_a, b_g, mu)  linear state x[j+3]
+  const int jb = lane - N;
+  const bool isfeat = lane < N;
+  const bool isatt = jb == 6;
+  const bool hasq = (isfeat && lane < len) || isatt;
+  const bool haslin = (isfeat && lane < len) || (jb >= 0 && jb < 14 && jb != 6);
+  int rid0, rid1, rid2;
+  if (isfeat) { rid0 = 16 + 3 * lane; rid1 = rid0 + 1; rid2 = rid0 + 2; }
+  else if (isatt) { rid0 = 6; rid1 = 7; rid2 = 8; }
+  else { const int r = (jb < 6) ? jb : ((jb < 14) ? jb + 2 : 0); rid0 = rid1 = rid2 = r; }
+  double* qptr = isfeat ? (xs + xZ + 5 * lane) : (xs + xATT);
+  double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0)));
+  const double rho_reset = 1.0 / (2.0 * prm.min_depth);
+  const double lam0 = partial ? S.lam[rid0] : 1.0, lam1 = partial ? S.lam[rid1] : 1.0, lam2 = partial ? S.lam[rid2] : 1.0;
+
   while (m < M) {
     const int slot = S.mslot[m];
     const int j0 = 16 + 3 * slot;
     const double* R = S.mR + 4 * m;
     const int mnext = res_next_valid(S, m + 1);
     const int slot_next = (mnext < M) ? S.mslot[mnext] : -1;
-    // ---- innovation covariance, gate, gain rows (vi_ekf_meas.cpp:232-247)
+    const double* Pr = S.Praw + pp * 2 * n;
+    // ---- innovation covariance and gate (vi_ekf_meas.cpp:232-239); the gain rows are computed by the workers
     const double* smr = sm + 8 * smp;
     double* smw = sm + 8 * (smp ^ 1);
-    const double h00 = smr[2], h01 = smr[3], h10 = smr[4], h11 = smr[5];
-    const double r0 = smr[6], r1 = smr[7];
+    const double2 hA = *reinterpret_cast<const double2*>(smr + 2), hB = *reinterpret_cast<const double2*>(smr + 4),
+                  rr = *reinterpret_cast<const double2*>(smr + 6);
+    const double2 pa = *reinterpret_cast<const double2*>(Pr + 2 * j0), pbv = *reinterpret_cast<const double2*>(Pr + 2 * j0 + 2);
+    const double2 Ra = *reinterpret_cast<const double2*>(R), Rb = *reinterpret_cast<const double2*>(R + 2);
+    const double2 p0 = *reinterpret_cast<const double2*>(Pr + 2 * rid0), p1 = *reinterpret_cast<const double2*>(Pr + 2 * rid1),
+                  p2 = *reinterpret_cast<const double2*>(Pr + 2 * rid2);
+    const double h00 = hA.x, h01 = hA.y, h10 = hB.x, h11 = hB.y, r0 = rr.x, r1 = rr.y;
     double Sm[4], Si[4];
     {
-      const double a0 = S.Praw[2 * j0 + 0], a1 = S.Praw[2 * j0 + 1], b0 = S.Praw[2 * (j0 + 1) + 0], b1 = S.Praw[2 * (j0 + 1) + 1];
-      const double w00 = a0 * h00 + a1 * h01, w01 = a0 * h10 + a1 * h11;
-      const double w10 = b0 * h00 + b1 * h01, w11 = b0 * h10 + b1 * h11;
-      Sm[0] = h00 * w00 + h01 * w10 + R[0];
-      Sm[1] = h00 * w01 + h01 * w11 + R[2];
-      Sm[2] = h10 * w00 + h11 * w10 + R[1];
-      Sm[3] = h10 * w01 + h11 * w11 + R[3];
+      const double w00 = pa.x * h00 + pa.y * h01, w01 = pa.x * h10 + pa.y * h11;
+      const double w10 = pbv.x * h00 + pbv.y * h01, w11 = pbv.x * h10 + pbv.y * h11;
+      Sm[0] = h00 * w00 + h01 * w10 + Ra.x;
+      Sm[1] = h00 * w01 + h01 * w11 + Rb.x;
+      Sm[2] = h10 * w00 + h11 * w10 + Ra.y;
+      Sm[3] = h10 * w01 + h11 * w11 + Rb.y;
     }
-    inv2(Sm, Si);
+    inv2_fast(Sm, Si);
     const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;
     const bool gated = mahal > 9.0;
-    double dv[3] = {0.0, 0.0, 0.0};   // lambda o (K r) of this lane's feature rows
+    if (lane == 0) {
+      *reinterpret_cast<double2*>(sm + 20) = make_double2(Si[0], Si[1]);
+      *reinterpret_cast<double2*>(sm + 22) = make_double2(Si[2], Si[3]);
+      sm[31] = gated ? 1.0 : 0.0;
+      sm[27] = 0.0;   // NaN-guard word, raised by any thread that sees a NaN gain row
+    }
+    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
+    __syncthreads();  // B2a : S^-1 and the gate verdict are published
+    __syncthreads();  // B2b : (workers wrote the gain rows Kt / Wt in between; this wave only passes through)
+    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
+    // ---- this lane's gain rows (registers only) and correction lambda o (K r)   (vi_ekf_meas.cpp:241-255)
+    double dv0, dv1, dv2;
     int bad = 0;
-    if (!gated) {
-      auto row = [&](int i, double& dxi) {
-        // feature rows come from the extracted columns; body rows from the LDS-resident body columns (symmetry)
-        const double2 pr = (i >= 16) ? *reinterpret_cast<const double2*>(S.Praw + 2 * i)
-                                     : make_double2(S.Pbc[(3 * slot + 0) * 16 + i], S.Pbc[(3 * slot + 1) * 16 + i]);
+    {
+      auto rowk = [&](const double2& pr, double l) {
         const double w0 = pr.x * h00 + pr.y * h01, w1 = pr.x * h10 + pr.y * h11;
         const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
-        *reinterpret_cast<double2*>(S.Wt + 2 * i) = make_double2(w0, w1);
-        *reinterpret_cast<double2*>(S.Kt + 2 * i) = make_double2(k0, k1);
         if (k0 != k0 || k1 != k1) bad = 1;
-        const double l = partial ? S.lam[i] : 1.0;
-        dxi = (l * k0) * r0 + (l * k1) * r1;
+        return (l * k0) * r0 + (l * k1) * r1;
       };
-      if (lane < N) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) row(16 + 3 * lane + q, dv[q]);
-      } else {
-        for (int i = lane - N; i < 16; i += nb) { double d; row(i, d); S.sm[32 + i] = d; }   // body dx -> LDS
-      }
+      dv0 = rowk(p0, lam0); dv1 = rowk(p1, lam1); dv2 = rowk(p2, lam2);
       if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
-      bad = __any(bad);
+      bad = __any(bad);   // the 64 lanes together cover every row of K
     }
-    if (lane == 0) sm[31] = gated ? 1.0 : (bad ? 2.0 : 0.0);
-    __syncthreads();  // B2
-    // ---- state correction x <- x [+] (lambda o K r), fix_depth, next prediction
-    const bool corr = !gated && !bad;
-    if (corr && lane == 63) {   // body (vi_ekf_helper.cpp:90-92)
-      double dxb[16], xo[17];
+    RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
+    const bool corr = !gated && !bad && !(S.dbg & 2);
+    // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
+    // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
+    double qn[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
+    double lin = *linptr;
+    if (corr) {
+      double t1[3], t2[3], zt[3], v[3], e[4];
+      bearing_frame_fast(qn, t1, t2, zt);
+      v[0] = isatt ? dv0 : (t1[0] * dv0 + t2[0] * dv1);
+      v[1] = isatt ? dv1 : (t1[1] * dv0 + t2[1] * dv1);
+      v[2] = isatt ? dv2 : (t1[2] * dv0 + t2[2] * dv1);
+      q_exp_fast(v, e);
+      double A[4], Bq[4];
 #pragma unroll
-      for (int i = 0; i < 16; i++) dxb[i] = S.sm[32 + i];
-      body_boxplus_fast(xs, dxb, xo);
-#pragma unroll
-      for (int i = 0; i < 17; i++) xs[i] = xo[i];
+      for (int i = 0; i < 4; i++) { A[i] = isatt ? qn[i] : e[i]; Bq[i] = isatt ? e[i] : qn[i]; }
+      q_otimes(A, Bq, qn);
+      lin += isfeat ? dv2 : dv0;
+      if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
     }
+    RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
     if (lane == 0) sm[28 + par] = 0.0;
-    if (lane < len)
-      res_feature_update(xs + xZ + 5 * lane, corr, !gated, dv[0], dv[1], dv[2], a.dp, &S.fixadd[par * N + lane],
-                         &S.fixset[par * N + lane], &sm[28 + par], &flag,
-                         (lane == slot_next) ? (S.mz + 2 * mnext) : nullptr, smw);
+    if (!gated && isfeat && lane < len) {   // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238)
+      double rho = lin;
+      if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
+      if (rho < 0.0) {
+        const double err = rho_reset - rho;
+        S.fixadd[par * N + lane] = err * err;
+        sm[28 + par] = 1.0;
+        rho = rho_reset;
+        flag |= FLAG_NEGDEPTH;
+      } else if (rho > 1e2) {
+        S.fixset[par * N + lane] = 1.0;
+        sm[28 + par] = 1.0;
+        rho = rho_reset;
+      }
+      lin = rho;
+    }
+    if (haslin && !(S.dbg & 2)) *linptr = lin;
+    if (lane == slot_next) {   // prediction for the next measurement from the corrected bearing (registers)
+      double zhat[2], Hb[4];
+      h_feat_fast(qn, prm, zhat, Hb);
+      const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mnext);
+      *reinterpret_cast<double2*>(smw + 2) = make_double2(Hb[0], Hb[1]);
+      *reinterpret_cast<double2*>(smw + 4) = make_double2(Hb[2], Hb[3]);
+      *reinterpret_cast<double2*>(smw + 6) = make_double2(zn.x - zhat[0], zn.y - zhat[1]);
+    }
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     par ^= 1;
     smp ^= 1;
+    pp ^= 1;
+    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 2);
     __syncthreads();  // B1
+    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 3);
+    it_++;
     m = mnext;
   }
 
+  RES_STAMP(S, lane == 0, 11);
   __syncthreads();  // B5
+  RES_STAMP(S, lane == 0, 12);
   // ---------------- store x, status ----------------
   double* xg = a.x + (long)S.b * a.nxs;
   for (int i = lane; i < xZ + 5 * len; i += 64) {
@@ -738,6 +920,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     xg[i] = v;
   }
   if (flag) atomicOr(&a.flags[S.b], flag);
+  RES_STAMP(S, lane == 0, 13);
 }
 
 template <int RB, int CB, int NW>
@@ -761,7 +944,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
-  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop; S.b = b;
+  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = do_prop >> 8; S.b = b; S.stamps = a.ws;
 
   // ---- common prologue: state, lambdas, mailboxes, measurement table (validity decided once, here)
   {
@@ -769,7 +952,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
-    if (tid == 0) { S.sm[30] = do_prop ? dt_all[b] : 0.0; S.sm[28] = 0.0; S.sm[29] = 0.0; }
+    if (tid == 0) { S.sm[30] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[28] = 0.0; S.sm[29] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
       const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];
@@ -784,7 +967,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
       if (code != 0 && result_all) result_all[(long)b * m_stride + mm_] = code;
     }
   }
+  RES_STAMP(S, tid == 0, 62);
   __syncthreads();
+  RES_STAMP(S, tid == 0, 63);
   if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
   else res_worker<RB, CB, TW>(a, S, TR, TC, tid);
 }
