@@ -133,18 +133,18 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   return VIEKF_OK;
 }
 
-// Resident instances <RB, CB, NW>: NW worker waves (+1 service wave) per workgroup; the worker thread grid
-// TR = ceil(N/RB) x TC = ceil(N/CB) must fit NW*64 threads.
-struct ResInst { int RB, CB, NW, nmin, nmax; };
+// Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the worker thread
+// grid is TR = ceil(N/RB) block-rows x TD = N/2 + 1 wrapped diagonals and must fit NW*64 threads.
+struct ResInst { int RB, NW, nmin, nmax; };
 const ResInst kResInst[] = {
-    {3, 2, 7, 1, 50},
+    {3, 7, 1, 50},
 };
 
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
                              const double*, long, long, int*);
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
-    case 0: return k_step_resident<3, 2, 7>;
+    case 0: return k_step_resident<3, 7>;
   }
   return nullptr;
 }
@@ -154,7 +154,7 @@ int setup_resident(viekf_batch* b) {
   for (int i = 0; i < (int)(sizeof(kResInst) / sizeof(kResInst[0])); i++) {
     const ResInst& r = kResInst[i];
     if (b->N < r.nmin || b->N > r.nmax) continue;
-    const int TR = (b->N + r.RB - 1) / r.RB, TC = (b->N + r.CB - 1) / r.CB;
+    const int TR = (b->N + r.RB - 1) / r.RB, TC = b->N / 2 + 1;   // TC holds TD, the number of wrapped diagonals
     if (TR * TC > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;

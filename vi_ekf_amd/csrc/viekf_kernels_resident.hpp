@@ -2,16 +2,15 @@
 // covariance lives in VGPRs for the complete step (propagate + M sequential feature updates), so
 // P crosses HBM once per step instead of (M+1) times.
 //
-// Ownership (DESIGN.md "resident layout"): the 3N x 3N feature part of P is a grid of 3x3 blocks
-// (I,J).  Threads form a TR x TC grid (tr = tid % TR, tc = tid / TR); thread (tr,tc) keeps the
-// RB x CB blocks  I = tr + TR*a,  J = tc + TC*c  in registers.  The 16 body rows/columns are cut
-// into 3-vectors: P[3I..3I+2, k] pieces go to the threads of block-row I's tr, P[k, 3J..3J+2]
-// pieces to the threads of block-column J's tc, P_bb one element per thread.  With this cartesian
-// ownership a rank-2 sweep needs K for RB block-rows and W for CB block-columns per thread, and
-// the propagation Phi P Phi^T + Gd Qu Gd^T becomes a register-tiled contraction
+// Ownership (DESIGN.md "resident layout"): the 3N x 3N feature part of P is a grid of 3x3 blocks (I,J).  P is
+// symmetric, so of every unordered pair {I,J} only ONE block is kept, on wrapped diagonals J = (I + d) mod N,
+// d = 0..N/2.  Worker threads form a TR x TD grid (tr = tid % TR, td = tid / TR); thread (tr,td) keeps the RB blocks
+// I = tr + TR*a of diagonal d = td in registers.  The 16 body columns P[:,0:16] live in LDS for the whole step (the
+// body rows are their mirror).  A rank-2 sweep needs K for the block's rows and W for its columns, and the propagation
+// Phi P Phi^T + Gd Qu Gd^T becomes a register-tiled contraction
 //     P+[I,J] = X_I Y_J^T + Phi_ff[I] P[I,J] Phi_ff[J]^T,   X_I = [U_I | Phi_fb[I] | Gd_I Qu],
 //                                                          Y_J = [Phi_fb[J] | V_J | Gd_J]   (K = 38)
-// with U = (Phi P)[feat, body], V_J = (P[b,J] Phi_ff[J]^T)^T staged in LDS.
+// with U = (Phi P)[feat, body], V_J = Phi_ff[J] P[J, body] staged in LDS.
 // lambda_feat is the same for every feature slot (vi_ekf.cpp:139-144), so the partial-update
 // mask Lambda (vi_ekf.cpp:83,146) is ONE 3x3 constant for every feature/feature block.
 #pragma once
@@ -25,7 +24,7 @@ namespace viekf {
 constexpr int XK = 38;  // contraction depth of the propagate GEMM: 16 (U) + 16 (Phi_fb) + 6 (Gd)
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, mslot, mz, mR, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, mslot, mz, mR, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
@@ -40,6 +39,7 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     T16 = take(256); xdb = take(16);
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
     Pbc = take(nf * 16);
+    PhibbT = take(256);
     mslot = take(32); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
@@ -309,7 +309,7 @@ constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lis
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
-      *xdb, *Pbc, *mz, *mR;
+      *xdb, *Pbc, *PhibbT, *mz, *mR;
   int* mslot;   // [MCAP] slot, or -(code+2) for a measurement that is not run (code -1/2/3 -> -1/-4/-5)
   BodyCtx* ctx;
   int N, n, nf, len, M, mstride, do_prop, b, dbg;
@@ -323,38 +323,41 @@ __device__ __forceinline__ int res_next_valid(const ResShared& S, int from) {
   return m;
 }
 
-template <int RB, int CB, int TW>
-__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TC, int tid) {
+template <int RB, int TW>
+__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
   double* P = a.P + (long)S.b * n * ld;
-  const int tr_ = tid % TR, tc_ = tid / TR;
+  // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept, on wrapped diagonals
+  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: rows I >= N/2 of
+  //   it are left unowned).  Thread (tr, td) of a TR x TD grid owns rows I = tr + TR*a (a < RB) of diagonal d = td.
+  const int tr_ = tid % TR, td_ = tid / TR;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
   double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
   // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
+  const bool evenN = (N & 1) == 0;
+  auto blk = [&](int tr, int td, int ia, int& I, int& J) -> bool {   // block ia of thread (tr,td); false = not owned
+    I = tr + TR * ia;
+    const bool v = td < TD && I < N && !(evenN && td == N / 2 && I >= N / 2);
+    I = min(I, N - 1);                    // clamped: every LDS / global read stays in range, results never stored
+    J = I + min(td, TD - 1);
+    if (J >= N) J -= N;
+    return v;
+  };
 
-  double pb[RB][CB][9];   // pb[a][c][r*3+s] = P[16+3I+r][16+3J+s]
+  double pb[RB][9];   // pb[a][r*3+s] = P[16+3I+r][16+3J+s]
   {
-    // element (ia,ic,r,s) lives at  P + [uniform: (16+r+3 TR ia) + (16+s+3 TC ic) ld] + [per thread: 3 tr + 3 tc ld]
-    // loads are unconditional (branch-free): out-of-range owners read a valid element that is never used
-    const int tr = opaque(tr_), tc = opaque(tc_);
-    const bool own = tc < TC;
-    const int toff = 3 * tr + 3 * tc * ld;
+    const int tr = opaque(tr_), td = opaque(td_);
 #pragma unroll
-    for (int ia = 0; ia < RB; ia++)
+    for (int ia = 0; ia < RB; ia++) {
+      int I, J;
+      blk(tr, td, ia, I, J);
+      const double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);
 #pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int I = tr + TR * ia, J = tc + TC * ic;
-        const bool v = own && I < N && J < N;
-        const int tsel = v ? toff : 0;
+      for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int s = 0; s < 3; s++)
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            const double* pu = P + (v ? ((16 + r + 3 * TR * ia) + (long)(16 + s + 3 * TC * ic) * ld) : 0L);
-            pb[ia][ic][r * 3 + s] = pu[tsel];
-          }
-      }
+        for (int r = 0; r < 3; r++) pb[ia][r * 3 + s] = pu[r + (long)s * ld];
+    }
     // body columns -> LDS (coalesced along rows)
     for (int e = tid; e < nf * 16; e += TW) {
       const int k = e / nf, row = e - k * nf;
@@ -372,6 +375,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 #pragma unroll
       for (int s = 0; s < 3; s++) Lff[r * 3 + s] = uniform_f64(prm.use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0);
   }
+  const double lfe[3] = {uniform_f64(a.lambda[16]), uniform_f64(a.lambda[17]), uniform_f64(a.lambda[18])};
   const bool partial = prm.use_partial_update != 0;
   int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
   RES_STAMP(S, tid == 0, 64);
@@ -391,7 +395,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       for (int k = 0; k < 16; k++) a2 += S.Abb[r * 16 + k] * S.Abb[k * 16 + c];
       const double id = (r == c) ? 1.0 : 0.0, av = S.Abb[e];
       Mbb[e] = id + av * dt / 2.0 + a2 * dt * dt / 6.0;
-      Phibb[e] = id + av * dt + a2 * dt * dt / 2.0;
+      const double ph = id + av * dt + a2 * dt * dt / 2.0;
+      Phibb[e] = ph;
+      S.PhibbT[c * 16 + r] = ph;   // transposed copy: lanes that differ in the OUTPUT column read consecutive words
     }
     __syncthreads();  // B2p : Phi_fb / Phi_ff / Gd rows ready (service), Phi_bb ready (workers)
 
@@ -437,63 +443,53 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     //      first each row times Phi_ff[J]^T, then each column times Phi_ff[I]  (keeps the register peak low)
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
+      const int tr = opaque(tr_), td = opaque(td_);
+      int I, J;
+      const bool v = blk(tr, td, ia, I, J);
+      const double* fj = phiff + 9 * J;
 #pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int tr = opaque(tr_), tc = opaque(tc_);
-        const bool own = tc < TC;
-        const int I = tr + TR * ia, J = tc + TC * ic;
-        const bool v = own && I < N && J < N;
-        const double* fj = phiff + 9 * min(J, N - 1);
+      for (int r = 0; r < 3; r++) {
+        const double p0 = pb[ia][r * 3 + 0], p1 = pb[ia][r * 3 + 1], p2 = pb[ia][r * 3 + 2];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const double p0 = pb[ia][ic][r * 3 + 0], p1 = pb[ia][ic][r * 3 + 1], p2 = pb[ia][ic][r * 3 + 2];
-#pragma unroll
-          for (int s = 0; s < 3; s++) pb[ia][ic][r * 3 + s] = p0 * fj[s * 3 + 0] + p1 * fj[s * 3 + 1] + p2 * fj[s * 3 + 2];
-        }
-        const double* fi = phiff + 9 * min(I, N - 1);
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-          const double p0 = pb[ia][ic][0 * 3 + s], p1 = pb[ia][ic][1 * 3 + s], p2 = pb[ia][ic][2 * 3 + s];
-#pragma unroll
-          for (int r = 0; r < 3; r++) pb[ia][ic][r * 3 + s] = fi[r * 3 + 0] * p0 + fi[r * 3 + 1] * p1 + fi[r * 3 + 2] * p2;
-        }
-        if (v && I == J) {
-          pb[ia][ic][0] += a.Qx[16 + 3 * I + 0];
-          pb[ia][ic][4] += a.Qx[16 + 3 * I + 1];
-          pb[ia][ic][8] += a.Qx[16 + 3 * I + 2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 3; s++) pb[ia][r * 3 + s] = p0 * fj[s * 3 + 0] + p1 * fj[s * 3 + 1] + p2 * fj[s * 3 + 2];
       }
+      const double* fi = phiff + 9 * I;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const double p0 = pb[ia][0 * 3 + s], p1 = pb[ia][1 * 3 + s], p2 = pb[ia][2 * 3 + s];
+#pragma unroll
+        for (int r = 0; r < 3; r++) pb[ia][r * 3 + s] = fi[r * 3 + 0] * p0 + fi[r * 3 + 1] * p1 + fi[r * 3 + 2] * p2;
+      }
+      if (v && I == J) {
+        pb[ia][0] += a.Qx[16 + 3 * I + 0];
+        pb[ia][4] += a.Qx[16 + 3 * I + 1];
+        pb[ia][8] += a.Qx[16 + 3 * I + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     RES_STAMP(S, tid == 0, 68);
     // ---- register-tiled contraction  P[I,J] += X_I Y_J^T  (K = 38)
 #pragma unroll 1
     for (int k = 0; k < XK; k += 2) {
-      const int tr = opaque(tr_), tc = opaque(tc_);
-      double2 yv[CB][3];
-#pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int J = min(tc + TC * ic, N - 1);
-#pragma unroll
-        for (int s = 0; s < 3; s++) yv[ic][s] = *reinterpret_cast<const double2*>(Y + (3 * J + s) * XK + k);
-      }
+      const int tr = opaque(tr_), td = opaque(td_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
-        const int I = min(tr + TR * ia, N - 1);
-        double2 xv[3];
+        int I, J;
+        blk(tr, td, ia, I, J);
+        double2 xv[3], yv[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) xv[r] = *reinterpret_cast<const double2*>(X + (3 * I + r) * XK + k);
 #pragma unroll
-        for (int ic = 0; ic < CB; ic++)
+        for (int s = 0; s < 3; s++) yv[s] = *reinterpret_cast<const double2*>(Y + (3 * J + s) * XK + k);
 #pragma unroll
-          for (int r = 0; r < 3; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-              double acc = pb[ia][ic][r * 3 + s];
-              acc = fma(xv[r].x, yv[ic][s].x, acc);
-              acc = fma(xv[r].y, yv[ic][s].y, acc);
-              pb[ia][ic][r * 3 + s] = acc;
-            }
+          for (int s = 0; s < 3; s++) {
+            double acc = pb[ia][r * 3 + s];
+            acc = fma(xv[r].x, yv[s].x, acc);
+            acc = fma(xv[r].y, yv[s].y, acc);
+            pb[ia][r * 3 + s] = acc;
+          }
       }
     }
     RES_STAMP(S, tid == 0, 69);
@@ -502,12 +498,21 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
       const int row = e >> 4, k = e & 15;
       const double* xr = X + row * XK;
+      const double* pt = S.PhibbT + k;          // Phi_bb[k][c] = PhibbT[c*16 + k]: conflict-free across the 16 k-lanes
       double s = 0.0;
-#pragma unroll 4
-      for (int c = 0; c < 16; c++) s += xr[c] * Phibb[k * 16 + c];
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const double2 xv = *reinterpret_cast<const double2*>(xr + c);
+        s = fma(xv.x, pt[c * 16], s);
+        s = fma(xv.y, pt[c * 16 + 16], s);
+      }
       double g = 0.0;
-#pragma unroll 2
-      for (int c = 0; c < 6; c++) g += xr[32 + c] * Gdb[k * 6 + c];
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const double2 xv = *reinterpret_cast<const double2*>(xr + 32 + c);
+        g = fma(xv.x, Gdb[k * 6 + c], g);
+        g = fma(xv.y, Gdb[k * 6 + c + 1], g);
+      }
       Pbc[e] = s + g;
     }
     for (int e = tid; e < 256; e += TW) {
@@ -527,42 +532,43 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     for (int e = tid; e < 256; e += TW) Pbb[e] = S.Mbb[e];
   }
 
-  // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks
+  // block indices of this thread, computed once (symmetric ownership left enough registers to keep them)
+  int Ib[RB], Jb[RB];
+  bool vb[RB];
+#pragma unroll
+  for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tr_, td_, ia, Ib[ia], Jb[ia]);
+  // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
   auto apply_fixes = [&](int mb) {
     if (S.sm[28 + mb] == 0.0) return;   // nothing posted (the common case): one uniform LDS read
-    const int tr = opaque(tr_), tc = opaque(tc_);
-    const bool own = tc < TC;
 #pragma unroll
-    for (int ia = 0; ia < RB; ia++)
-#pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int I = tr + TR * ia, J = tc + TC * ic;
-        if (own && I == J && I < len) {
-          const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
-          if (ad != 0.0) { pb[ia][ic][8] += ad; S.fixadd[mb * N + I] = 0.0; }
-          if (st != 0.0) { pb[ia][ic][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
-        }
+    for (int ia = 0; ia < RB; ia++) {
+      const int I = Ib[ia];
+      if (vb[ia] && td_ == 0 && I < len) {
+        const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
+        if (ad != 0.0) { pb[ia][8] += ad; S.fixadd[mb * N + I] = 0.0; }
+        if (st != 0.0) { pb[ia][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
       }
+    }
   };
-  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into the
-  // Praw buffer `buf`
-  auto extract_cols = [&](int slot, int buf) {
-    const int tr = opaque(tr_), tc = opaque(tc_);
-    const int cc = slot / TC, ct = slot - cc * TC;
+  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into the Praw
+  // buffer `buf`: the pair {I, slot} is held either as block (I, slot) or, transposed, as block (slot, J = I)
+  auto extract_cols = [&](int slot, int buf, const int* Ib_, const int* Jb_, const bool* vb_) {
     double* Pw = S.Praw + buf * 2 * n;
-    if (tc == ct) {
 #pragma unroll
-      for (int ic = 0; ic < CB; ic++)
-        if (ic == cc) {
-#pragma unroll
-          for (int ia = 0; ia < RB; ia++) {
-            const int I = tr + TR * ia;
-            if (I < N)
-#pragma unroll
-              for (int r = 0; r < 3; r++)
-                *reinterpret_cast<double2*>(Pw + 2 * (16 + 3 * I + r)) = make_double2(pb[ia][ic][r * 3 + 0], pb[ia][ic][r * 3 + 1]);
-          }
-        }
+    for (int ia = 0; ia < RB; ia++) {
+      const int I = Ib_[ia], J = Jb_[ia];
+      const bool asrow = J == slot;             // block (I, slot): its columns 0,1 are the wanted column pair
+      const bool ascol = !asrow && I == slot;   // block (slot, J): its rows 0,1, transposed
+      if (vb_[ia] && (asrow || ascol)) {
+        const int base = 16 + 3 * (asrow ? I : J);
+        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch)
+        const double a0 = pb[ia][0], a1 = asrow ? pb[ia][1] : pb[ia][3];
+        const double b0 = asrow ? pb[ia][3] : pb[ia][1], b1 = pb[ia][4];
+        const double c0 = asrow ? pb[ia][6] : pb[ia][2], c1 = asrow ? pb[ia][7] : pb[ia][5];
+        *reinterpret_cast<double2*>(Pw + 2 * (base + 0)) = make_double2(a0, a1);
+        *reinterpret_cast<double2*>(Pw + 2 * (base + 1)) = make_double2(b0, b1);
+        *reinterpret_cast<double2*>(Pw + 2 * (base + 2)) = make_double2(c0, c1);
+      }
     }
   };
   // body rows of those columns = rows 3 slot, 3 slot + 1 of the LDS-resident body columns (symmetry)
@@ -577,7 +583,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   int m = res_next_valid(S, 0);
   if (m < S.M) {
     apply_fixes(par ^ 1);
-    extract_cols(S.mslot[m], 0);
+    extract_cols(S.mslot[m], 0, Ib, Jb, vb);
     extract_body(S.mslot[m], 0);
   }
   RES_STAMP(S, tid == 0, 71);
@@ -611,70 +617,77 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const bool run = S.sm[31] == 0.0 && S.sm[27] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     apply_fixes(par ^ 1);
     if (run) {
-      const int tr = opaque(tr_), tc = opaque(tc_);   // recompute addresses per iteration (no hoist + spill)
-      double2 wJ[CB][3];
-#pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int J = min(tc + TC * ic, N - 1);
-#pragma unroll
-        for (int s = 0; s < 3; s++) wJ[ic][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * J + s));
-      }
+      const int it = tid;
+      // ---- issue every LDS read of this phase up front (registers are plentiful with symmetric ownership), then compute
+      double2 kI[RB][3], wJ[RB][3];
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
-        const int I = min(tr + TR * ia, N - 1);
-        double2 kI[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) kI[r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * I + r));
+        for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * Ib[ia] + r));
 #pragma unroll
-        for (int ic = 0; ic < CB; ic++)
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int s = 0; s < 3; s++) {
-              const double t = fma(kI[r].y, wJ[ic][s].y, kI[r].x * wJ[ic][s].x);
-              pb[ia][ic][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][ic][r * 3 + s]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * Jb[ia] + s));
       }
+      // body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
+      // 8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
+      const bool hasc = it < 8 * N;
+      const int g = min(it >> 3, N - 1), j2 = (it & 7) * 2;
+      const double2 cw0 = *reinterpret_cast<const double2*>(S.Wt + 2 * j2);
+      const double2 cw1 = *reinterpret_cast<const double2*>(S.Wt + 2 * j2 + 2);
+      const double2 clk = *reinterpret_cast<const double2*>(S.lam + j2);
+      double2 cki[3], cpv[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        cki[q] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * g + q));
+        cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
+      }
+      // body block: 2 adjacent elements per thread, on the top 128 threads
+      const int ib = it - (TW - 128);
+      const int br = max(ib, 0) >> 3, bc2 = (max(ib, 0) & 7) * 2;
+      const double2 bkr = *reinterpret_cast<const double2*>(S.Kt + 2 * br);
+      const double2 bw0 = *reinterpret_cast<const double2*>(S.Wt + 2 * bc2);
+      const double2 bw1 = *reinterpret_cast<const double2*>(S.Wt + 2 * bc2 + 2);
+      const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
+      const double blr = S.lam[br];
+      double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
+
+      // ---- feature/feature blocks (registers)
+#pragma unroll
+      for (int ia = 0; ia < RB; ia++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const double t = fma(kI[ia][r].y, wJ[ia][s].y, kI[ia][r].x * wJ[ia][s].x);
+            pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
+          }
       RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
-      // body columns, in LDS: item = (row, half): 8 consecutive k of one row (general Lambda_ik: body lambdas differ).
-      // The two rows that are the next measurement's columns are published into the other Praw buffer on the fly.
-      double* Pn = S.Praw + (pp ^ 1) * 2 * n;
-      for (int e = opaque(tid); e < 2 * nf; e += TW) {
-        const int row = e >> 1, k0 = (e & 1) * 8;
-        const double2 ki = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + row));
-        const double li = S.lam[16 + row];
-        double* pr = Pbc + row * 16 + k0;
-        const int cn = row - 3 * slot_next;   // 0 / 1 -> this row is column cn of the next measurement
-        const bool pub = slot_next >= 0 && (cn == 0 || cn == 1);
+      // ---- body columns
+      {
+        double* Pn = S.Praw + (pp ^ 1) * 2 * n;
+        const bool pubg = hasc && g == slot_next;
 #pragma unroll
-        for (int h = 0; h < 8; h += 2) {
-          const double2 w0 = *reinterpret_cast<const double2*>(S.Wt + 2 * (k0 + h));
-          const double2 w1 = *reinterpret_cast<const double2*>(S.Wt + 2 * (k0 + h + 1));
-          const double2 lk = *reinterpret_cast<const double2*>(S.lam + k0 + h);
-          double2 pv = *reinterpret_cast<double2*>(pr + h);
-          const double L0 = partial ? (lk.x + li - li * lk.x) : 1.0, L1 = partial ? (lk.y + li - li * lk.y) : 1.0;
-          pv.x = fma(-L0, fma(ki.y, w0.y, ki.x * w0.x), pv.x);
-          pv.y = fma(-L1, fma(ki.y, w1.y, ki.x * w1.x), pv.y);
-          *reinterpret_cast<double2*>(pr + h) = pv;
-          if (pub) { Pn[2 * (k0 + h) + cn] = pv.x; Pn[2 * (k0 + h + 1) + cn] = pv.y; }
+        for (int q = 0; q < 3; q++) {
+          const double L0 = partial ? (clk.x + lfe[q] - lfe[q] * clk.x) : 1.0;
+          const double L1 = partial ? (clk.y + lfe[q] - lfe[q] * clk.y) : 1.0;
+          cpv[q].x = fma(-L0, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
+          cpv[q].y = fma(-L1, fma(cki[q].y, cw1.y, cki[q].x * cw1.x), cpv[q].y);
+          if (hasc) *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
+          if (pubg && q < 2) { Pn[2 * j2 + q] = cpv[q].x; Pn[2 * (j2 + 1) + q] = cpv[q].y; }   // next measurement's body rows
         }
-      }
-      RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
-      for (int e = opaque(tid); e < 256; e += TW) {   // body block
-        const int r = e >> 4, c = e & 15;
-        const double2 kr = *reinterpret_cast<const double2*>(S.Kt + 2 * r);
-        const double2 wc = *reinterpret_cast<const double2*>(S.Wt + 2 * c);
-        const double lr = S.lam[r], lc = S.lam[c];
-        const double Lm = partial ? (lc + lr - lr * lc) : 1.0;
-        Pbb[e] = fma(-Lm, fma(kr.y, wc.y, kr.x * wc.x), Pbb[e]);
+        RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
+        if (ib >= 0) {
+          const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
+          bpv.x = fma(-L0, fma(bkr.y, bw0.y, bkr.x * bw0.x), bpv.x);
+          bpv.y = fma(-L1, fma(bkr.y, bw1.y, bkr.x * bw1.x), bpv.y);
+          *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
+        }
       }
     } else if (slot_next >= 0) {
       extract_body(slot_next, pp ^ 1);   // nothing was swept: the body columns are unchanged
     }
     par ^= 1;
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 2);
-    if (slot_next >= 0) extract_cols(slot_next, pp ^ 1);   // reads the swept registers
+    if (slot_next >= 0) extract_cols(slot_next, pp ^ 1, Ib, Jb, vb);   // reads the swept registers
     // NOTE: a fix_depth edit touches P(rho,rho) only, never the zeta columns just extracted
     pp ^= 1;
     smp ^= 1;
@@ -690,23 +703,25 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // ---------------- store ----------------
   // (indices re-derived from opaque copies: otherwise the load addresses are kept alive -- spilled -- all kernel long)
   {
-    const int tr = opaque(tr_), tc = opaque(tc_);
-    const bool own = tc < TC;
-    const int toff = 3 * tr + 3 * tc * ld;
+    const int tr = opaque(tr_), td = opaque(td_);
 #pragma unroll
-    for (int ia = 0; ia < RB; ia++)
+    for (int ia = 0; ia < RB; ia++) {
+      int I, J;
+      if (blk(tr, td, ia, I, J)) {
+        double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);   // block (I,J)
+        double* pt = P + ((16 + 3 * J) + (long)(16 + 3 * I) * ld);   // its mirror (J,I)
 #pragma unroll
-      for (int ic = 0; ic < CB; ic++) {
-        const int I = tr + TR * ia, J = tc + TC * ic;
-        if (own && I < N && J < N)
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+          for (int r = 0; r < 3; r++) pu[r + (long)s * ld] = pb[ia][r * 3 + s];
+        if (I != J) {
 #pragma unroll
           for (int s = 0; s < 3; s++)
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-              double* pu = P + ((16 + r + 3 * TR * ia) + (long)(16 + s + 3 * TC * ic) * ld);
-              pu[toff] = pb[ia][ic][r * 3 + s];
-            }
+            for (int r = 0; r < 3; r++) pt[s + (long)r * ld] = pb[ia][r * 3 + s];
+        }
       }
+    }
     for (int e = opaque(tid); e < nf * 16; e += TW) {     // body columns, coalesced along rows
       const int k = e / nf, row = e - k * nf;
       P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];
@@ -923,8 +938,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   RES_STAMP(S, lane == 0, 13);
 }
 
-template <int RB, int CB, int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, int TR, int TC, int do_prop,
+template <int RB, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
                                                                 const double* __restrict__ z_all,
@@ -940,7 +955,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
   S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.X = smem + L.X; S.Y = smem + L.Y;
   S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
-  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc;
+  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT;
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
@@ -971,7 +986,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   __syncthreads();
   RES_STAMP(S, tid == 0, 63);
   if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
-  else res_worker<RB, CB, TW>(a, S, TR, TC, tid);
+  else res_worker<RB, TW>(a, S, TR, TD, tid);
 }
 
 }  // namespace viekf
