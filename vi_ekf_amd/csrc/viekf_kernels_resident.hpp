@@ -745,6 +745,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   unsigned flag = 0;
   const bool partial = prm.use_partial_update != 0;
   int par = 0;
+  // the per-update critical path runs on this wave: let it win the issue arbitration against its SIMD-mate worker wave
+  __builtin_amdgcn_s_setprio(3);
   RES_STAMP(S, lane == 0, 0);
   __syncthreads();  // B0
   RES_STAMP(S, lane == 0, 1);
