@@ -141,6 +141,15 @@ int viekf_batch_init_feature(viekf_batch *b, const double *pix /*[batch][2]*/, c
 int viekf_batch_update_feat(viekf_batch *b, const double *z, const int32_t *slot, int32_t M, const double *R,
                             int32_t r_mode, int32_t *result, viekf_mem where);
 
+/* ONE measurement of any model of the reference's table per filter: VIEKF::update with
+ * h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, src/vi_ekf/vi_ekf_meas.cpp:196-386.
+ * type: viekf_meas_type.  z [batch][zdim] (ATT/QZETA: quaternion, zdim 4).  R: rdim x rdim column-major,
+ * r_mode 0 = shared, 1 = R[batch][rdim*rdim].  slot [batch]: local feature index for QZETA/FEAT/DEPTH/INV_DEPTH
+ * (NULL otherwise).  active [batch] (NULL = all active): an inactive measurement only runs fix_depth, as in the
+ * reference (:230).  result [batch]: viekf_meas_result. */
+int viekf_batch_update(viekf_batch *b, int32_t type, const double *z, int32_t zdim, const double *R, int32_t rdim,
+                       int32_t r_mode, const int32_t *slot, const uint8_t *active, int32_t *result, viekf_mem where);
+
 /* one hot-path step = propagate + M feature updates, fused where the kernel family allows */
 int viekf_batch_step(viekf_batch *b, const double *u, const double *dt, const double *z, const int32_t *slot,
                      int32_t M, const double *R, int32_t r_mode, int32_t *result, viekf_mem where);

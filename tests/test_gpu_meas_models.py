@@ -1,0 +1,89 @@
+"""GPU parity of the generic measurement update (every model of the reference's table, reference
+src/vi_ekf/vi_ekf_meas.cpp:281-386) against the CPU oracle, through viekf_batch_update."""
+import numpy as np
+import pytest
+
+import vi_ekf_amd as v
+from oracle import oracle as orc
+from vi_ekf_amd import scene
+from tests.test_gpu_parity import assert_close, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(B, N, seed, over=None):
+    sc = scene.make_scene(B, N, 2, seed=seed, params=over or {})
+    g = v.BatchVIEKF(B, N, sc["params"])
+    fs = []
+    for b in range(B):
+        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+        fs.append(f)
+    for i in range(N):
+        g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        for b in range(B):
+            fs[b].init_feature(sc["pix"][b, i], i)
+    # two hot-path steps first so that P is dense and x is off its initial value
+    for s in range(2):
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+        for b in range(B):
+            fs[b].run_steps(sc["u"][s, b][None], sc["dt"][b], sc["z"][s, b][None], sc["slot"][b], sc["R"])
+    return sc, g, fs
+
+
+def check(g, fs, what):
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x after " + what)
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after " + what)
+
+
+@pytest.mark.parametrize("N,drag", [(4, 1), (12, 0)])
+def test_all_measurement_models(N, drag):
+    B = 3
+    sc, g, fs = setup(B, N, 60 + N, dict(use_drag_term=drag))
+    r = np.random.default_rng(5)
+    x = np.stack([f.x.copy() for f in fs])
+    slot = np.array([0, N - 1, N // 2], dtype=np.int32)
+
+    def run(mtype, z, R, use_slot=False, active=None):
+        res = g.update(mtype, z, R, slot if use_slot else None, active)
+        exp = np.array([fs[b].update(mtype, z[b], R, True if active is None else bool(active[b]),
+                                     int(slot[b]) if use_slot else -1) for b in range(B)], dtype=np.int32)
+        assert (res == exp).all(), (mtype, res, exp)
+        check(g, fs, "type %d" % mtype)
+
+    # ACC: drag form (2-D) or gravity form (3-D)  (vi_ekf_meas.cpp:281-306)
+    if drag:
+        run(orc.ACC, x[:, 10:12] - x[:, 16:17] * x[:, 3:5] + r.normal(0, 0.1, (B, 2)), np.diag([1.0, 1.0]))
+    else:
+        run(orc.ACC, np.tile([0.0, 0.0, -9.80665], (B, 1)) + r.normal(0, 0.1, (B, 3)), np.diag([1.0, 1.0, 1.0]))
+    run(orc.ALT, -x[:, 2:3] + r.normal(0, 0.05, (B, 1)), np.array([[0.1]]))
+    qz = np.stack([orc.q_boxplus(x[b, 6:10], r.normal(0, 0.02, 3)) for b in range(B)])
+    run(orc.ATT, qz, np.diag([0.01] * 3))
+    run(orc.POS, x[:, 0:3] + r.normal(0, 0.05, (B, 3)), np.diag([0.1] * 3))
+    run(orc.VEL, x[:, 3:6] + r.normal(0, 0.05, (B, 3)), np.diag([0.1] * 3))
+    qf = np.stack([orc.q_feat_boxplus(fs[b].x[17 + 5 * slot[b]:21 + 5 * slot[b]], r.normal(0, 0.01, 2)) for b in range(B)])
+    run(orc.QZETA, qf, np.diag([0.01, 0.01]), use_slot=True)
+    dep = np.stack([[1.0 / fs[b].x[21 + 5 * slot[b]] + r.normal(0, 0.05)] for b in range(B)])
+    run(orc.DEPTH, dep, np.array([[0.5]]), use_slot=True)
+    rho = np.stack([[fs[b].x[21 + 5 * slot[b]] + r.normal(0, 0.01)] for b in range(B)])
+    run(orc.INV_DEPTH, rho, np.array([[0.05]]), use_slot=True)
+    zf = np.stack([fs[b].h(orc.FEAT, None, int(slot[b]))[0][:2] + r.normal(0, 0.5, 2) for b in range(B)])
+    run(orc.FEAT, zf, sc["R"], use_slot=True)
+    # an inactive measurement only runs fix_depth (vi_ekf_meas.cpp:230); mixed active mask
+    run(orc.POS, x[:, 0:3] + 0.3, np.diag([0.1] * 3), active=np.array([0, 1, 0], dtype=np.uint8))
+    # gating: a far-off position fix is rejected and leaves the filter untouched
+    res = g.update(orc.POS, x[:, 0:3] + 50.0, np.diag([0.1] * 3))
+    assert (res == 1).all()
+    for b in range(B):
+        assert fs[b].update(orc.POS, x[b, 0:3] + 50.0, np.diag([0.1] * 3), True, -1) == 1
+    check(g, fs, "gated POS")
+
+
+def test_result_codes_for_bad_inputs():
+    B, N = 3, 4
+    sc, g, fs = setup(B, N, 71)
+    z = np.array([[1.0], [np.nan], [2.0]])
+    slot = np.array([0, 1, N + 3], dtype=np.int32)
+    res = g.update(orc.INV_DEPTH, z, np.array([[0.05]]), slot)
+    assert res[1] == 2 and res[2] == 3        # MEAS_NAN, MEAS_INVALID (slot out of range)
+    with pytest.raises(v.ViekfError):
+        g.update(orc.PIXEL_VEL, np.zeros((B, 2)), np.eye(2))

@@ -186,6 +186,28 @@ class BatchVIEKF:
         self._keep = []
         return result
 
+    def update(self, mtype, z, R, slot=None, active=None):
+        """ONE measurement of any reference model per filter (reference vi_ekf_meas.cpp:196-386); host arrays.
+        z [B][zdim]; R (rdim,rdim) shared or (B,rdim,rdim); slot [B] for feature models -> result [B]"""
+        self._keep = []
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        zdim = z.shape[1]
+        R = np.asarray(R, dtype=np.float64)
+        rdim = R.shape[-1]
+        if R.ndim == 2:
+            r_mode, Rc = 0, np.ascontiguousarray(R.T)
+        else:
+            r_mode, Rc = 1, np.ascontiguousarray(R.transpose(0, 2, 1))
+        pz, w = self._arg(z, np.float64, (self.B, zdim), None)
+        pR, w = self._arg(Rc, np.float64, Rc.shape, w)
+        ps, w = self._arg(slot, np.int32, (self.B,), w)
+        pa, w = self._arg(active, np.uint8, (self.B,), w)
+        res = np.empty(self.B, dtype=np.int32)
+        capi.check(capi.lib().viekf_batch_update(self._h, int(mtype), pz, zdim, pR, rdim, r_mode, ps, pa,
+                                                 C.c_void_p(res.ctypes.data), capi.HOST))
+        self._keep = []
+        return res
+
     def step(self, u, dt, z, slot, R, result=None):
         """one hot-path step: propagate + M feature updates"""
         self._keep = []

@@ -559,6 +559,44 @@ int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
   return VIEKF_OK;
 }
 
+int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zdim, const double* R, int32_t rdim,
+                       int32_t r_mode, const int32_t* slot, const uint8_t* active, int32_t* result, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!z || !R) return fail(VIEKF_ERR_INVALID, "z and R must not be null");
+  if (type < 0 || type >= VIEKF_TOTAL_MEAS || type == VIEKF_PIXEL_VEL)
+    return fail(VIEKF_ERR_UNSUPPORTED, "measurement type not supported (PIXEL_VEL is an empty TODO in the reference)");
+  if (zdim < 1 || zdim > 4 || rdim < 1 || rdim > 3 || r_mode < 0 || r_mode > 1)
+    return fail(VIEKF_ERR_INVALID, "need 1 <= zdim <= 4, 1 <= rdim <= 3, r_mode 0 or 1");
+  const bool needs_slot = type == VIEKF_QZETA || type == VIEKF_FEAT || type == VIEKF_DEPTH || type == VIEKF_INV_DEPTH;
+  if (needs_slot && !slot) return fail(VIEKF_ERR_INVALID, "slot must not be null for feature measurements");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B, rr = (size_t)rdim * rdim;
+  const double *d_z = nullptr, *d_R = nullptr;
+  const int32_t* d_slot = nullptr;
+  const uint8_t* d_act = nullptr;
+  int32_t* d_res = nullptr;
+  if (where == VIEKF_HOST) {
+    if (int rc = stage_begin(b, stage_size(sizeof(double) * B * zdim) + stage_size(sizeof(double) * B * rr) +
+                                    stage_size(sizeof(int32_t) * B) * 2 + stage_size(B)))
+      return rc;
+  }
+  if (int rc = in_ptr(b, z, B * zdim, where, &d_z)) return rc;
+  if (int rc = in_ptr(b, R, r_mode ? B * rr : rr, where, &d_R)) return rc;
+  if (int rc = in_ptr(b, slot, B, where, &d_slot)) return rc;
+  if (int rc = in_ptr(b, active, B, where, &d_act)) return rc;
+  if (result) d_res = where == VIEKF_DEVICE ? result : static_cast<int32_t*>(stage_take(b, sizeof(int32_t) * B));
+  StreamArgs a = make_args(b);
+  const size_t lds = sizeof(double) * (size_t)(b->nxs + 7 * b->n + 64);
+  hipLaunchKernelGGL(k_update_generic<kThreads>, dim3(b->B), dim3(kThreads), lds, b->stream, a, type, zdim, rdim, d_z,
+                     d_slot, d_R, r_mode ? (long)rr : 0L, d_act, d_res);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (result) HIP_TRY(hipMemcpyAsync(result, d_res, sizeof(int32_t) * B, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
 int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot, int32_t M, const double* R,
                             int32_t r_mode, int32_t* result, viekf_mem where) {
   return update_or_step(b, nullptr, nullptr, false, z, slot, M, R, r_mode, result, where);

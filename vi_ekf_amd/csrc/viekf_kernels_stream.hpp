@@ -418,6 +418,238 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
 }
 
 // ------------------------------------------------------------------------------------------------
+// generic measurement update: VIEKF::update for every measurement model of the reference's table
+// (vi_ekf_meas.cpp:196-278 with h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, :281-386).
+// Each H has at most 6 non-zero columns, so W = P H^T is a combination of <= 6 columns of P and the update is the same
+// rank-r sweep  P_ij -= Lambda_ij (K_i . W_j)  as for FEAT.  One workgroup per filter, P in HBM/L2 (these models run at
+// IMU / truth rate, one per propagate -- not the N-per-frame hot loop).
+// ------------------------------------------------------------------------------------------------
+constexpr int MT_ACC = 0, MT_ALT = 1, MT_ATT = 2, MT_POS = 3, MT_VEL = 4, MT_QZETA = 5, MT_FEAT = 6, MT_DEPTH = 8,
+              MT_INV_DEPTH = 9;   // include/vi_ekf.h:113-124
+
+__device__ __forceinline__ void q_log_dev(const double* q, double* o) {   // src/quat.cpp:82-98
+  const double nv = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (nv < 1e-8) { o[0] = o[1] = o[2] = 0.0; }
+  else { const double s = 2.0 * atan2(nv, q[0]) / nv; o[0] = s * q[1]; o[1] = s * q[2]; o[2] = s * q[3]; }
+}
+__device__ __forceinline__ void q_boxminus_dev(const double* q1, const double* q2, double* o) {   // src/quat.cpp:319-327
+  const double inv[4] = {q2[0], -q2[1], -q2[2], -q2[3]};
+  double dq[4];
+  q_otimes(inv, q1, dq);
+  if (dq[0] < 0.0) { dq[0] = -dq[0]; dq[1] = -dq[1]; dq[2] = -dq[2]; dq[3] = -dq[3]; }
+  q_log_dev(dq, o);
+}
+__device__ __forceinline__ void q_feat_boxminus_dev(const double* qj, const double* qi, double* o) {   // math_helper.h:25-43
+  double t1[3], t2[3], zi[3], a1[3], a2[3], zj[3];
+  bearing_frame(qi, t1, t2, zi);
+  bearing_frame(qj, a1, a2, zj);
+  const double d[3] = {zi[0] - zj[0], zi[1] - zj[1], zi[2] - zj[2]};
+  if (sqrt(dot3(d, d)) > 1e-8) {
+    double s[3];
+    cross3(zi, zj, s);
+    const double ns = sqrt(dot3(s, s));
+    const double th = acos(dot3(zi, zj));
+    s[0] = s[0] / ns * th; s[1] = s[1] / ns * th; s[2] = s[2] / ns * th;
+    o[0] = dot3(t1, s); o[1] = dot3(t2, s);
+  } else { o[0] = 0.0; o[1] = 0.0; }
+}
+// r x r inverse (r <= 3) by LU with partial pivoting, row-major (Eigen's dynamic-size inverse, vi_ekf_meas.cpp:232)
+__device__ __forceinline__ void small_inverse_dev(int r, const double* S, double* Si) {
+  double a[9], b[9];
+  for (int i = 0; i < r; i++) for (int j = 0; j < r; j++) { a[i * 3 + j] = S[i * r + j]; b[i * 3 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < r; c++) {
+    int piv = c; double best = fabs(a[c * 3 + c]);
+    for (int i = c + 1; i < r; i++) if (fabs(a[i * 3 + c]) > best) { best = fabs(a[i * 3 + c]); piv = i; }
+    if (piv != c) for (int j = 0; j < r; j++) {
+      double t = a[c * 3 + j]; a[c * 3 + j] = a[piv * 3 + j]; a[piv * 3 + j] = t;
+      t = b[c * 3 + j]; b[c * 3 + j] = b[piv * 3 + j]; b[piv * 3 + j] = t;
+    }
+    for (int i = c + 1; i < r; i++) {
+      const double l = a[i * 3 + c] / a[c * 3 + c];
+      for (int j = 0; j < r; j++) { a[i * 3 + j] -= l * a[c * 3 + j]; b[i * 3 + j] -= l * b[c * 3 + j]; }
+    }
+  }
+  for (int j = 0; j < r; j++)
+    for (int i = r - 1; i >= 0; i--) {
+      double s = b[i * 3 + j];
+      for (int k = i + 1; k < r; k++) s -= a[i * 3 + k] * Si[k * r + j];
+      Si[i * r + j] = s / a[i * 3 + i];
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, int zdim, int rdim,
+                                                      const double* __restrict__ z_all, const int* __restrict__ slot_all,
+                                                      const double* __restrict__ R_all, long r_stride_b,
+                                                      const unsigned char* __restrict__ active_all,
+                                                      int* __restrict__ result_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, ld = a.ld;
+  const DevParams& prm = *a.dp;
+  double* xs = smem;            // [nxs]
+  double* W = xs + a.nxs;       // [n][3]
+  double* K = W + 3 * n;        // [n][3]
+  double* lam = K + 3 * n;      // [n]
+  double* sm = lam + n;         // [64]: hcols (int as double) [0..5], Hc [6..23] (3 rows x 6 cols), res [24..26], ncol [27], Si [28..36], verdict [37]
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const int len = a.len[b];
+  const int nact = 16 + 3 * len;
+  const int slot = slot_all ? slot_all[b] : 0;
+  const bool active = active_all ? active_all[b] != 0 : true;
+  int* res_out = result_all ? &result_all[b] : nullptr;
+  unsigned flag = 0;
+  const bool needs_slot = type == MT_QZETA || type == MT_FEAT || type == MT_DEPTH || type == MT_INV_DEPTH;
+  if (needs_slot && (slot < 0 || slot >= len)) { if (res_out && tid == 0) *res_out = (slot < 0) ? -1 : 3; return; }
+  const double* z = z_all + (long)b * zdim;
+  {
+    bool isnan_ = false;
+    for (int i = 0; i < zdim; i++) isnan_ |= z[i] != z[i];
+    if (isnan_) { if (res_out && tid == 0) *res_out = 2; return; }   // MEAS_NAN
+  }
+  for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
+  for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
+  __syncthreads();
+
+  if (tid == 0) {   // measurement model: zhat, the non-zero columns of H, residual
+    int cols[6]; double Hc[18]; int nc = 0; double zhat[4] = {0, 0, 0, 0}; double r3[3] = {0, 0, 0};
+    for (int i = 0; i < 18; i++) Hc[i] = 0.0;
+    auto col = [&](int c) { cols[nc] = c; return nc++; };
+    if (type == MT_ACC) {                                       // vi_ekf_meas.cpp:281-306
+      if (prm.use_drag_term) {
+        const double mu = xs[xMU];
+        zhat[0] = -mu * xs[xVEL] + xs[xB_A]; zhat[1] = -mu * xs[xVEL + 1] + xs[xB_A + 1];
+        int c;
+        c = col(dxVEL); Hc[0 * 6 + c] = -mu;  c = col(dxVEL + 1); Hc[1 * 6 + c] = -mu;
+        c = col(dxB_A); Hc[0 * 6 + c] = 1.0;  c = col(dxB_A + 1); Hc[1 * 6 + c] = 1.0;
+        c = col(dxMU); Hc[0 * 6 + c] = -xs[xVEL]; Hc[1 * 6 + c] = -xs[xVEL + 1];
+      } else {
+        const double g[3] = {0.0, 0.0, kGravity}; double gB[3], ng[3], Sk[9];
+        q_rotp(xs + xATT, g, gB);
+        for (int i = 0; i < 3; i++) { zhat[i] = xs[xB_A + i] - gB[i]; ng[i] = -1.0 * gB[i]; }
+        skew3(ng, Sk);
+        for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); for (int i = 0; i < 3; i++) Hc[i * 6 + c] = Sk[i * 3 + j]; }
+        for (int j = 0; j < 3; j++) { const int c = col(dxB_A + j); Hc[j * 6 + c] = 1.0; }
+      }
+    } else if (type == MT_ALT) { zhat[0] = -xs[xPOS + 2]; const int c = col(dxPOS + 2); Hc[c] = -1.0; }
+    else if (type == MT_ATT) { for (int i = 0; i < 4; i++) zhat[i] = xs[xATT + i]; for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); Hc[j * 6 + c] = 1.0; } }
+    else if (type == MT_POS) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xPOS + j]; const int c = col(dxPOS + j); Hc[j * 6 + c] = 1.0; } }
+    else if (type == MT_VEL) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xVEL + j]; const int c = col(dxVEL + j); Hc[j * 6 + c] = 1.0; } }
+    else if (type == MT_QZETA) { for (int i = 0; i < 4; i++) zhat[i] = xs[xZ + 5 * slot + i]; for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[j * 6 + c] = 1.0; } }
+    else if (type == MT_FEAT) {
+      double Hb[4]; h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
+      for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[0 * 6 + c] = Hb[0 * 2 + j]; Hc[1 * 6 + c] = Hb[1 * 2 + j]; }
+    } else if (type == MT_DEPTH) { const double rho = xs[xZ + 5 * slot + 4]; zhat[0] = 1.0 / rho; const int c = col(dxZ + 3 * slot + 2); Hc[c] = -1.0 / (rho * rho); }
+    else if (type == MT_INV_DEPTH) { zhat[0] = xs[xZ + 5 * slot + 4]; const int c = col(dxZ + 3 * slot + 2); Hc[c] = 1.0; }
+    if (type == MT_QZETA) q_feat_boxminus_dev(z, zhat, r3);           // :210-213
+    else if (type == MT_ATT) q_boxminus_dev(z, zhat, r3);             // :214-217
+    else for (int i = 0; i < zdim && i < 3; i++) r3[i] = z[i] - zhat[i];
+    for (int i = 0; i < 6; i++) sm[i] = (i < nc) ? (double)cols[i] : 0.0;
+    for (int i = 0; i < 18; i++) sm[6 + i] = Hc[i];
+    sm[24] = r3[0]; sm[25] = r3[1]; sm[26] = r3[2]; sm[27] = (double)nc;
+  }
+  __syncthreads();
+  if (!active) {   // :230 -- an inactive measurement only runs fix_depth (and the logger)
+    for (int f = tid; f < len; f += T) fix_depth_one(xs, P, ld, f, prm, flag);
+    __syncthreads();
+    for (int i = tid; i < xZ + 5 * len; i += T) xg[i] = xs[i];
+    if (res_out && tid == 0) *res_out = 0;
+    if (flag) atomicOr(&a.flags[b], flag);
+    return;
+  }
+  const int nc = (int)sm[27];
+  // W = P H^T  (n x r): combination of the nc non-zero columns
+  for (int i = tid; i < nact; i += T) {
+    double w[3] = {0.0, 0.0, 0.0};
+    for (int c = 0; c < nc; c++) {
+      const double pv = P[i + (long)((int)sm[c]) * ld];
+      for (int q = 0; q < rdim; q++) w[q] += pv * sm[6 + q * 6 + c];
+    }
+    for (int q = 0; q < 3; q++) W[3 * i + q] = w[q];
+  }
+  __syncthreads();
+  if (tid == 0) {   // S = H W[cols] + R, inverse, gate
+    const double* R = R_all + (long)b * r_stride_b;   // column-major rdim x rdim
+    double S[9], Si[9];
+    for (int p = 0; p < rdim; p++)
+      for (int q = 0; q < rdim; q++) {
+        double s = 0.0;
+        for (int c = 0; c < nc; c++) s += sm[6 + p * 6 + c] * W[3 * (int)sm[c] + q];
+        S[p * rdim + q] = s + R[p + q * rdim];
+      }
+    small_inverse_dev(rdim, S, Si);
+    double mahal = 0.0;
+    for (int q = 0; q < rdim; q++) { double t = 0.0; for (int p = 0; p < rdim; p++) t += sm[24 + p] * Si[p * rdim + q]; mahal += t * sm[24 + q]; }
+    for (int i = 0; i < 9; i++) sm[28 + i] = (i < rdim * rdim) ? Si[i] : 0.0;
+    sm[37] = (mahal > 9.0) ? 1.0 : 0.0;   // :234-239
+  }
+  __syncthreads();
+  if (sm[37] != 0.0) { if (res_out && tid == 0) *res_out = 1; return; }   // gated: returns before fix_depth
+  int bad = 0;
+  for (int i = tid; i < nact; i += T) {
+    for (int q = 0; q < 3; q++) {
+      double k = 0.0;
+      if (q < rdim) for (int p = 0; p < rdim; p++) k += W[3 * i + p] * sm[28 + p * rdim + q];
+      K[3 * i + q] = k;
+      if (k != k) bad = 1;
+    }
+  }
+  for (int i = 0; i < 18; i++) if (sm[6 + i] != sm[6 + i]) bad = 1;
+  bad = __syncthreads_or(bad);
+  if (!bad) {
+    const bool partial = prm.use_partial_update != 0;
+    if (tid == 0) {
+      double dxb[16], xo[17];
+      for (int i = 0; i < 16; i++) {
+        const double l = partial ? lam[i] : 1.0;
+        double s = 0.0;
+        for (int q = 0; q < rdim; q++) s += (l * K[3 * i + q]) * sm[24 + q];
+        dxb[i] = s;
+      }
+      body_boxplus(xs, dxb, xo);
+      for (int i = 0; i < 17; i++) xs[i] = xo[i];
+    }
+    for (int f = tid; f < len; f += T) {
+      const int d = 16 + 3 * f;
+      double dv[3];
+      for (int e = 0; e < 3; e++) {
+        const double l = partial ? lam[d + e] : 1.0;
+        double s = 0.0;
+        for (int q = 0; q < rdim; q++) s += (l * K[3 * (d + e) + q]) * sm[24 + q];
+        dv[e] = s;
+      }
+      double qn[4];
+      q_feat_boxplus(xs + xZ + 5 * f, dv[0], dv[1], qn);
+      double* xf = xs + xZ + 5 * f;
+      xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
+      xf[4] += dv[2];
+    }
+    const long tot = (long)nact * nact;
+    for (long e = tid; e < tot; e += T) {
+      const int i = (int)(e % nact), j = (int)(e / nact);
+      double t = 0.0;
+      for (int q = 0; q < rdim; q++) t += K[3 * i + q] * W[3 * j + q];
+      const double li = lam[i], lj = lam[j];
+      const double L = partial ? (lj + li - li * lj) : 1.0;
+      P[i + (long)j * ld] -= L * t;
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < len; f += T) fix_depth_one(xs, P, ld, f, prm, flag);
+  __syncthreads();
+  for (int i = tid; i < xZ + 5 * len; i += T) {
+    const double v = xs[i];
+    if (v != v) flag |= FLAG_NAN;
+    if (v > 1e6) flag |= FLAG_BLOWUP;
+    xg[i] = v;
+  }
+  if (res_out && tid == 0) *res_out = 0;
+  if (flag) atomicOr(&a.flags[b], flag);
+}
+
+// ------------------------------------------------------------------------------------------------
 // init_feature (vi_ekf_feat.cpp:6-47), one workgroup per filter
 // ------------------------------------------------------------------------------------------------
 template <int T>
