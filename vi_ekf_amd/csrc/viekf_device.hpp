@@ -166,10 +166,14 @@ VD void body_ctx(const double* x, const double* ub, const DevParams& p, BodyCtx&
 }
 
 // Body dynamics + Jacobians (vi_ekf_dyn.cpp:42-80).  A is 16x16 row-major, G 16x6 row-major, xdot 16.
+// ZERO = false: the caller has already cleared xdot / A / G (e.g. cooperatively, one word per lane)
+template <bool ZERO = true>
 VD void body_dynamics(const BodyCtx& c, const DevParams& p, double* xdot, double* A, double* G) {
-  for (int i = 0; i < 16; i++) xdot[i] = 0.0;
-  for (int i = 0; i < 256; i++) A[i] = 0.0;
-  for (int i = 0; i < 96; i++) G[i] = 0.0;
+  if (ZERO) {
+    for (int i = 0; i < 16; i++) xdot[i] = 0.0;
+    for (int i = 0; i < 256; i++) A[i] = 0.0;
+    for (int i = 0; i < 96; i++) G[i] = 0.0;
+  }
   double wxv[3];
   cross3(c.omega, c.vel, wxv);
   // pdot = q.rota(vel) = R^T vel

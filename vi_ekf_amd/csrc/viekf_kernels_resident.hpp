@@ -24,22 +24,28 @@ namespace viekf {
 constexpr int XK = 38;  // contraction depth of the propagate GEMM: 16 (U) + 16 (Phi_fb) + 6 (Gd)
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, mslot, mz, mR, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, featA, mslot, mz, mR, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
-    Kt = take(2 * n); Wt = take(2 * n); Praw = take(4 * n); lam = take(n);   // Praw: two buffers of [n][2]
-    sm = take(48);   // [0..15] two prediction mailboxes, [28..29] fix mailboxes non-empty, [30] dt, [31] gate verdict, [32..47] body dx
+    Kt = take(2 * n); Wt = take(2 * n);
+    Praw = take(4 * n > 256 ? 4 * n : 256);   // two buffers of [n][2]; doubles as the 16x16 scratch T16 of the propagate
+    lam = take(n);
+    sm = take(64);   // [0..15],[16..31] two measurement mailboxes {Hb(4) res(2) Sinv(4) verdict}, [40..41] fix mailboxes
+                     // non-empty, [42] dt, [44..45] NaN-guard words (one per mailbox)
+    Pd = take(4 * (N > 0 ? N : 1));   // zeta-zeta 2x2 diagonal blocks, handed from the workers to the service lanes
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
     X = take(nf * XK); Y = take(nf * XK);
     phiff = take(9 * (N > 0 ? N : 1));
     Abb = take(256); Gb = take(96); Phibb = take(256); Mbb = take(256); Gdb = take(96); Pbb = take(256);
-    T16 = take(256); xdb = take(16);
+    T16 = Praw;   // 16x16 scratch of the propagate only: shares storage with the (update-phase) column buffers
+    xdb = take(16);
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
     Pbc = take(nf * 16);
     PhibbT = take(256);
+    featA = take(36 * (N > 0 ? N : 1));
     mslot = take(32); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
@@ -145,21 +151,22 @@ __device__ RES_INLINE void res_body_phase(const double* xs, const double* u, con
   q_rota(p->q_b_u, u, ub);
   q_rota(p->q_b_u, u + 3, ub + 3);
   body_ctx(xs, ub, *p, *ctx);
-  body_dynamics(*ctx, *p, xdb, Abb, Gb);
+  body_dynamics<false>(*ctx, *p, xdb, Abb, Gb);   // the service wave cleared xdb / Abb / Gb cooperatively
 }
 
-// one feature's share of the propagate set-up: dynamics -> rows of X / Y / phiff, state step
-__device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* xs, const BodyCtx* ctx,
-                                               const DevParams* p, const double* Abb, const double* Gb, double* X,
-                                               double* Y, double* phiff) {
-  double* Xr = X + (3 * f) * XK;
-  double* Yr = Y + (3 * f) * XK;
+// one feature's share of the propagate set-up on the SERVICE wave: dynamics, Phi_ff, state step.  The 3x16 rows of Phi_fb
+// and the input-noise rows Gd_f (both need the body Jacobian) are finished by the worker waves from featA:
+//   featA[f] = { Afv(9), Afg(9), Aff(9), Gff(9) }   with Gff = (I + Aff dt/2 + Aff^2 dt^2/6) Afg
+constexpr int FEATA = 36;
+__device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* xs, const BodyCtx* ctx, double* featA,
+                                             double* phiff) {
+  double* fa = featA + FEATA * f;
   if (f < len) {
     double xd3[3], Afv[9], Afg[9], Aff[9];
     const double* qz = xs + xZ + 5 * f;
     const double rho = qz[4];
     feature_dynamics(qz, rho, *ctx, xd3, Afv, Afg, Aff);
-    double Aff2[9], Mff[9];
+    double Aff2[9], Mff[9], Gff[9];
     mm<3, 3, 3>(Aff, Aff, Aff2);
 #pragma unroll
     for (int e = 0; e < 9; e++) {
@@ -167,62 +174,16 @@ __device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* 
       Mff[e] = id + Aff[e] * dt / 2.0 + Aff2[e] * dt * dt / 6.0;
       phiff[9 * f + e] = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
     }
-    double gacc[18];
+    mm<3, 3, 3>(Mff, Afg, Gff);
 #pragma unroll
-    for (int e = 0; e < 18; e++) gacc[e] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; c++) {
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        double afb = 0.0;
-        if (c >= dxVEL && c < dxVEL + 3) afb = Afv[r * 3 + (c - dxVEL)];
-        else if (c >= dxB_G && c < dxB_G + 3) afb = Afg[r * 3 + (c - dxB_G)];
-        double a2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-          a2 += Afv[r * 3 + k] * Abb[(dxVEL + k) * 16 + c] + Afg[r * 3 + k] * Abb[(dxB_G + k) * 16 + c];
-        if (c >= dxVEL && c < dxVEL + 3) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) a2 += Aff[r * 3 + k] * Afv[k * 3 + (c - dxVEL)];
-        } else if (c >= dxB_G && c < dxB_G + 3) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) a2 += Aff[r * 3 + k] * Afg[k * 3 + (c - dxB_G)];
-        }
-        const double ph = afb * dt + a2 * dt * dt / 2.0;
-        Xr[r * XK + 16 + c] = ph;
-        Yr[r * XK + c] = ph;
-        const double mfb = afb * dt / 2.0 + a2 * dt * dt / 6.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) gacc[r * 6 + k] += mfb * Gb[c * 6 + k];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; m++) s += Mff[r * 3 + m] * Afg[m * 3 + k];
-        gacc[r * 6 + 3 + k] += s;
-      }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double g = gacc[r * 6 + k] * dt;
-        Yr[r * XK + 32 + k] = g;
-        Xr[r * XK + 32 + k] = g * p->Qu[k];
-      }
+    for (int e = 0; e < 9; e++) { fa[e] = Afv[e]; fa[9 + e] = Afg[e]; fa[18 + e] = Aff[e]; fa[27 + e] = Gff[e]; }
     double qn[4];
     q_feat_boxplus_fast(qz, xd3[0] * dt, xd3[1] * dt, qn);
     double* xf = xs + xZ + 5 * f;
     xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
     xf[4] = rho + xd3[2] * dt;
   } else {  // inactive slot: Phi = I, G = 0
-    for (int r = 0; r < 3; r++) {
-      for (int c = 0; c < 16; c++) { Xr[r * XK + 16 + c] = 0.0; Yr[r * XK + c] = 0.0; }
-      for (int k = 0; k < 6; k++) { Xr[r * XK + 32 + k] = 0.0; Yr[r * XK + 32 + k] = 0.0; }
-    }
+    for (int e = 0; e < FEATA; e++) fa[e] = 0.0;
     for (int e = 0; e < 9; e++) phiff[9 * f + e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
   }
 }
@@ -309,7 +270,7 @@ constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lis
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
-      *xdb, *Pbc, *PhibbT, *mz, *mR;
+      *xdb, *Pbc, *PhibbT, *Pd, *featA, *mz, *mR;
   int* mslot;   // [MCAP] slot, or -(code+2) for a measurement that is not run (code -1/2/3 -> -1/-4/-5)
   BodyCtx* ctx;
   int N, n, nf, len, M, mstride, do_prop, b, dbg;
@@ -385,7 +346,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   if (S.do_prop) {
     double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
     double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
-    const double dt = S.sm[30];
+    const double dt = S.sm[42];
     __syncthreads();  // B1p : body Jacobian ready (service)
 
     for (int e = tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303)
@@ -399,8 +360,50 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       Phibb[e] = ph;
       S.PhibbT[c * 16 + r] = ph;   // transposed copy: lanes that differ in the OUTPUT column read consecutive words
     }
-    __syncthreads();  // B2p : Phi_fb / Phi_ff / Gd rows ready (service), Phi_bb ready (workers)
+    __syncthreads();  // B2p : feature Jacobian blocks featA / Phi_ff ready (service), Phi_bb ready (workers)
 
+    // Phi_fb rows (vi_ekf.cpp:302-303 restricted to the feature/body block): one (feature row, body column) per item
+    //   A_fb = [.. Afv(VEL) .. Afg(B_G) ..],  (A^2)_fb = A_fb A_bb + A_ff A_fb
+#pragma unroll 1
+    for (int e = tid; e < nf * 16; e += TW) {
+      const int row = e >> 4, c = e & 15, f = row / 3, r = row - 3 * f;
+      const double* fa = S.featA + FEATA * f;
+      const bool cv = c >= dxVEL && c < dxVEL + 3, cg = c >= dxB_G && c < dxB_G + 3;
+      const int cc = cv ? (c - dxVEL) : (cg ? (c - dxB_G) : 0);
+      const double* blk3 = cv ? fa : fa + 9;            // Afv or Afg
+      const double afb = (cv || cg) ? blk3[r * 3 + cc] : 0.0;
+      double a2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        a2 += fa[r * 3 + k] * S.Abb[(dxVEL + k) * 16 + c] + fa[9 + r * 3 + k] * S.Abb[(dxB_G + k) * 16 + c];
+      if (cv || cg) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) a2 += fa[18 + r * 3 + k] * blk3[k * 3 + cc];
+      }
+      const double ph = afb * dt + a2 * dt * dt / 2.0;
+      X[row * XK + 16 + c] = ph;
+      Y[row * XK + c] = ph;
+    }
+    __syncthreads();  // B2q
+
+    // input-noise rows Gd_f = (M_fb G_b + [0 | Gff]) dt  -> Y[.,32..37], times Qu -> X[.,32..37]   (vi_ekf.cpp:302), with
+    //   M_fb = A_fb dt/2 + (A^2)_fb dt^2/6 = Phi_fb / 3 + A_fb dt/6   (A_fb has only the VEL and B_G columns)
+    for (int e = tid; e < nf * 6; e += TW) {
+      const int row = e / 6, k = e - 6 * row, f = row / 3, r = row - 3 * f;
+      const double* fa = S.featA + FEATA * f;
+      const double* phr = Y + row * XK;
+      double g = 0.0;
+#pragma unroll 4
+      for (int c = 0; c < 16; c++) g += phr[c] * S.Gb[c * 6 + k];
+      double ga = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; j++) ga += fa[r * 3 + j] * S.Gb[(dxVEL + j) * 6 + k] + fa[9 + r * 3 + j] * S.Gb[(dxB_G + j) * 6 + k];
+      g = g / 3.0 + ga * dt / 6.0;
+      if (k >= 3) g += fa[27 + r * 3 + (k - 3)];
+      g *= dt;
+      Y[row * XK + 32 + k] = g;
+      X[row * XK + 32 + k] = g * prm.Qu[k];
+    }
     for (int e = tid; e < 96; e += TW) {
       const int r = e / 6, k = e % 6;
       double s = 0.0;
@@ -539,7 +542,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tr_, td_, ia, Ib[ia], Jb[ia]);
   // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
   auto apply_fixes = [&](int mb) {
-    if (S.sm[28 + mb] == 0.0) return;   // nothing posted (the common case): one uniform LDS read
+    if (S.sm[40 + mb] == 0.0) return;   // nothing posted (the common case): one uniform LDS read
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
       const int I = Ib[ia];
@@ -581,40 +584,43 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // ---------------- M sequential feature updates: covariance side ----------------
   int smp = 0, pp = 0;
   int m = res_next_valid(S, 0);
+  // hand the zeta-zeta 2x2 of every diagonal block to the service lanes (they keep it current from here on)
+#pragma unroll
+  for (int ia = 0; ia < RB; ia++)
+    if (vb[ia] && td_ == 0) {
+      *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia]) = make_double2(pb[ia][0], pb[ia][1]);
+      *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia] + 2) = make_double2(pb[ia][3], pb[ia][4]);
+    }
   if (m < S.M) {
     apply_fixes(par ^ 1);
     extract_cols(S.mslot[m], 0, Ib, Jb, vb);
     extract_body(S.mslot[m], 0);
   }
   RES_STAMP(S, tid == 0, 71);
-  __syncthreads();  // B1
+  __syncthreads();  // Bp
+  __syncthreads();  // B1 : the service published the first measurement's {Hb, res, S^-1, verdict}
   int it_ = 0;
   while (m < S.M) {
     const int mnext = res_next_valid(S, m + 1);
     const int slot_next = (mnext < S.M) ? S.mslot[mnext] : -1;
-    // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T needs only the prediction -> before B2a;  K_i = W_i S^-1 after it
-    const int irow = min(opaque(tid), n - 1);
-    double w0, w1;
-    bool hnan;
-    {
-      const double* smr = S.sm + 8 * smp;
-      const double2 hA = *reinterpret_cast<const double2*>(smr + 2), hB = *reinterpret_cast<const double2*>(smr + 4);
+    const double* mbx = S.sm + 16 * smp;
+    const bool gated = mbx[10] != 0.0;
+    // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241)
+    if (tid < n && !gated) {
+      const int irow = tid;
+      const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2);
+      const double2 sA = *reinterpret_cast<const double2*>(mbx + 6), sB = *reinterpret_cast<const double2*>(mbx + 8);
       const double2 pr = *reinterpret_cast<const double2*>(S.Praw + pp * 2 * n + 2 * irow);
-      w0 = pr.x * hA.x + pr.y * hA.y; w1 = pr.x * hB.x + pr.y * hB.y;
-      hnan = hA.x != hA.x || hA.y != hA.y || hB.x != hB.x || hB.y != hB.y;
-      if (tid < n) *reinterpret_cast<double2*>(S.Wt + 2 * irow) = make_double2(w0, w1);
+      const double w0 = pr.x * hA.x + pr.y * hA.y, w1 = pr.x * hB.x + pr.y * hB.y;
+      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
+      *reinterpret_cast<double2*>(S.Wt + 2 * irow) = make_double2(w0, w1);
+      *reinterpret_cast<double2*>(S.Kt + 2 * irow) = make_double2(k0, k1);
+      if (k0 != k0 || k1 != k1 || hA.x != hA.x || hA.y != hA.y || hB.x != hB.x || hB.y != hB.y) S.sm[44 + smp] = 1.0;
     }
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 0);
-    __syncthreads();  // B2a : S^-1 and the gate verdict are in LDS
-    if (tid < n) {   // (vi_ekf_meas.cpp:241)
-      const double2 sA = *reinterpret_cast<const double2*>(S.sm + 20), sB = *reinterpret_cast<const double2*>(S.sm + 22);
-      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
-      *reinterpret_cast<double2*>(S.Kt + 2 * irow) = make_double2(k0, k1);
-      if (k0 != k0 || k1 != k1 || hnan) S.sm[27] = 1.0;
-    }
-    __syncthreads();  // B2b : gain vectors Kt / Wt are in LDS
+    __syncthreads();  // B2 : gain vectors Kt / Wt are in LDS
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
-    const bool run = S.sm[31] == 0.0 && S.sm[27] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
+    const bool run = !gated && S.sm[44 + smp] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     apply_fixes(par ^ 1);
     if (run) {
       const int it = tid;
@@ -752,14 +758,18 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   RES_STAMP(S, lane == 0, 1);
 
   if (S.do_prop) {
-    const double dt = sm[30];
+    const double dt = sm[42];
+    for (int i = lane; i < 256; i += 64) S.Abb[i] = 0.0;
+    for (int i = lane; i < 96; i += 64) S.Gb[i] = 0.0;
+    if (lane < 16) S.xdb[lane] = 0.0;
     if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
     RES_STAMP(S, lane == 0, 2);
     __syncthreads();  // B1p
     RES_STAMP(S, lane == 0, 3);
-    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, a.dp, S.Abb, S.Gb, S.X, S.Y, S.phiff);
+    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, S.featA, S.phiff);
     RES_STAMP(S, lane == 0, 4);
     __syncthreads();  // B2p
+    __syncthreads();  // B2q (workers expand featA into the Phi_fb rows)
     RES_STAMP(S, lane == 0, 5);
     if (lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
       double dxb[16], xo[17];
@@ -769,10 +779,10 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
 #pragma unroll
       for (int i = 0; i < 17; i++) xs[i] = xo[i];
     }
-    if (lane == 0) sm[28 + par] = 0.0;
+    if (lane == 0) sm[40 + par] = 0.0;
     for (int f = lane; f < len; f += 64)   // fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
       res_feature_update(xs + xZ + 5 * f, false, true, 0.0, 0.0, 0.0, a.dp, &S.fixadd[par * N + f],
-                         &S.fixset[par * N + f], &sm[28 + par], &flag, nullptr, nullptr);
+                         &S.fixset[par * N + f], &sm[40 + par], &flag, nullptr, nullptr);
     par ^= 1;
     RES_STAMP(S, lane == 0, 6);
     __syncthreads();  // B3p
@@ -780,20 +790,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
   }
-
-  int smp = 0;   // which half of the prediction mailbox (Hb, residual) the gain step reads
-  int pp = 0;    // which Praw buffer holds the current measurement's columns
-  int m = res_next_valid(S, 0);
-  if (m < M) {
-    const int slot = S.mslot[m];
-    if (lane == 0)
-      res_feature_update(xs + xZ + 5 * slot, false, false, 0.0, 0.0, 0.0, a.dp, nullptr, nullptr, nullptr, &flag,
-                         S.mz + 2 * m, sm);
-  }
-  RES_STAMP(S, lane == 0, 9);
-  __syncthreads();  // B1
-  RES_STAMP(S, lane == 0, 10);
-  int it_ = 0;
 
   // lane roles for the state correction (one instruction stream, no divergence):
   //   lane f < N           : feature f  -> rows 16+3f..+2 : bearing quaternion (2 rows) + inverse depth (1 row)
@@ -813,57 +809,81 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0)));
   const double rho_reset = 1.0 / (2.0 * prm.min_depth);
   const double lam0 = partial ? S.lam[rid0] : 1.0, lam1 = partial ? S.lam[rid1] : 1.0, lam2 = partial ? S.lam[rid2] : 1.0;
+  // Lambda of the zeta-zeta 2x2 block (lambda_feat[0], lambda_feat[1])
+  const double lz0 = a.lambda[16], lz1 = a.lambda[17];
+  const double L00 = partial ? (lz0 + lz0 - lz0 * lz0) : 1.0, L01 = partial ? (lz0 + lz1 - lz0 * lz1) : 1.0,
+               L11 = partial ? (lz1 + lz1 - lz1 * lz1) : 1.0;
+
+  // Each feature lane keeps its own P_zeta,zeta (2x2) current through the updates, so the lane of the NEXT measurement can
+  // form  S = Hb P_zz Hb^T + R,  S^-1  and the gate verdict right after its prediction -- at the END of an iteration.
+  // The next iteration then starts directly with the gain rows: no separate innovation phase, two barriers per update.
+  int smp = 0;   // which measurement mailbox holds the CURRENT measurement {Hb, res, S^-1, verdict}
+  int pp = 0;    // which Praw buffer holds the current measurement's columns
+  int m = res_next_valid(S, 0);
+  RES_STAMP(S, lane == 0, 9);
+  __syncthreads();  // Bp : the workers published Pd (diagonal zeta blocks) and the first measurement's columns
+  double pf00 = 0.0, pf01 = 0.0, pf10 = 0.0, pf11 = 0.0;
+  if (isfeat) { const double* pd = S.Pd + 4 * lane; pf00 = pd[0]; pf01 = pd[1]; pf10 = pd[2]; pf11 = pd[3]; }
+  // prediction + innovation of measurement mm (slot == this lane's feature) into mailbox half `hh`, from registers
+  auto predict = [&](const double* qf, int mm, int hh) {
+    double zhat[2], Hb[4], Sm[4], Si[4];
+    h_feat_fast(qf, prm, zhat, Hb);
+    const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mm);
+    const double* R = S.mR + 4 * mm;
+    const double r0 = zn.x - zhat[0], r1 = zn.y - zhat[1];
+    const double w00 = pf00 * Hb[0] + pf01 * Hb[1], w01 = pf00 * Hb[2] + pf01 * Hb[3];   // (P_zz Hb^T)
+    const double w10 = pf10 * Hb[0] + pf11 * Hb[1], w11 = pf10 * Hb[2] + pf11 * Hb[3];
+    Sm[0] = Hb[0] * w00 + Hb[1] * w10 + R[0];
+    Sm[1] = Hb[0] * w01 + Hb[1] * w11 + R[2];
+    Sm[2] = Hb[2] * w00 + Hb[3] * w10 + R[1];
+    Sm[3] = Hb[2] * w01 + Hb[3] * w11 + R[3];
+    inv2_fast(Sm, Si);
+    const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;   // vi_ekf_meas.cpp:234
+    double* mb = sm + 16 * hh;
+    *reinterpret_cast<double2*>(mb + 0) = make_double2(Hb[0], Hb[1]);
+    *reinterpret_cast<double2*>(mb + 2) = make_double2(Hb[2], Hb[3]);
+    *reinterpret_cast<double2*>(mb + 4) = make_double2(r0, r1);
+    *reinterpret_cast<double2*>(mb + 6) = make_double2(Si[0], Si[1]);
+    *reinterpret_cast<double2*>(mb + 8) = make_double2(Si[2], Si[3]);
+    mb[10] = (mahal > 9.0) ? 1.0 : 0.0;                                                   // gate (:235-239)
+  };
+  if (m < M && lane == S.mslot[m]) {
+    const double q0[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
+    predict(q0, m, 0);
+  }
+  __syncthreads();  // B1
+  RES_STAMP(S, lane == 0, 10);
+  int it_ = 0;
 
   while (m < M) {
-    const int slot = S.mslot[m];
-    const int j0 = 16 + 3 * slot;
-    const double* R = S.mR + 4 * m;
     const int mnext = res_next_valid(S, m + 1);
     const int slot_next = (mnext < M) ? S.mslot[mnext] : -1;
     const double* Pr = S.Praw + pp * 2 * n;
-    // ---- innovation covariance and gate (vi_ekf_meas.cpp:232-239); the gain rows are computed by the workers
-    const double* smr = sm + 8 * smp;
-    double* smw = sm + 8 * (smp ^ 1);
-    const double2 hA = *reinterpret_cast<const double2*>(smr + 2), hB = *reinterpret_cast<const double2*>(smr + 4),
-                  rr = *reinterpret_cast<const double2*>(smr + 6);
-    const double2 pa = *reinterpret_cast<const double2*>(Pr + 2 * j0), pbv = *reinterpret_cast<const double2*>(Pr + 2 * j0 + 2);
-    const double2 Ra = *reinterpret_cast<const double2*>(R), Rb = *reinterpret_cast<const double2*>(R + 2);
+    const double* mbx = sm + 16 * smp;
+    const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2),
+                  rr = *reinterpret_cast<const double2*>(mbx + 4), sA = *reinterpret_cast<const double2*>(mbx + 6),
+                  sB = *reinterpret_cast<const double2*>(mbx + 8);
+    const bool gated = mbx[10] != 0.0;
     const double2 p0 = *reinterpret_cast<const double2*>(Pr + 2 * rid0), p1 = *reinterpret_cast<const double2*>(Pr + 2 * rid1),
                   p2 = *reinterpret_cast<const double2*>(Pr + 2 * rid2);
     const double h00 = hA.x, h01 = hA.y, h10 = hB.x, h11 = hB.y, r0 = rr.x, r1 = rr.y;
-    double Sm[4], Si[4];
-    {
-      const double w00 = pa.x * h00 + pa.y * h01, w01 = pa.x * h10 + pa.y * h11;
-      const double w10 = pbv.x * h00 + pbv.y * h01, w11 = pbv.x * h10 + pbv.y * h11;
-      Sm[0] = h00 * w00 + h01 * w10 + Ra.x;
-      Sm[1] = h00 * w01 + h01 * w11 + Rb.x;
-      Sm[2] = h10 * w00 + h11 * w10 + Ra.y;
-      Sm[3] = h10 * w01 + h11 * w11 + Rb.y;
-    }
-    inv2_fast(Sm, Si);
-    const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;
-    const bool gated = mahal > 9.0;
-    if (lane == 0) {
-      *reinterpret_cast<double2*>(sm + 20) = make_double2(Si[0], Si[1]);
-      *reinterpret_cast<double2*>(sm + 22) = make_double2(Si[2], Si[3]);
-      sm[31] = gated ? 1.0 : 0.0;
-      sm[27] = 0.0;   // NaN-guard word, raised by any thread that sees a NaN gain row
-    }
+    const double Si[4] = {sA.x, sA.y, sB.x, sB.y};
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
-    __syncthreads();  // B2a : S^-1 and the gate verdict are published
-    __syncthreads();  // B2b : (workers wrote the gain rows Kt / Wt in between; this wave only passes through)
+    __syncthreads();  // B2 : (the workers wrote the gain rows Kt / Wt; this wave only passes through)
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
     // ---- this lane's gain rows (registers only) and correction lambda o (K r)   (vi_ekf_meas.cpp:241-255)
     double dv0, dv1, dv2;
+    double kw[8];   // rows 0,1 of this lane: (w0,w1,k0,k1) each -- for the lane's own P_zz update
     int bad = 0;
     {
-      auto rowk = [&](const double2& pr, double l) {
+      auto rowk = [&](const double2& pr, double l, double* keep) {
         const double w0 = pr.x * h00 + pr.y * h01, w1 = pr.x * h10 + pr.y * h11;
         const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
         if (k0 != k0 || k1 != k1) bad = 1;
+        if (keep) { keep[0] = w0; keep[1] = w1; keep[2] = k0; keep[3] = k1; }
         return (l * k0) * r0 + (l * k1) * r1;
       };
-      dv0 = rowk(p0, lam0); dv1 = rowk(p1, lam1); dv2 = rowk(p2, lam2);
+      dv0 = rowk(p0, lam0, kw); dv1 = rowk(p1, lam1, kw + 4); dv2 = rowk(p2, lam2, nullptr);
       if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
       bad = __any(bad);   // the 64 lanes together cover every row of K
     }
@@ -886,34 +906,32 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       q_otimes(A, Bq, qn);
       lin += isfeat ? dv2 : dv0;
       if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
+      // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
+      pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
+      pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
+      pf10 = fma(-L01, fma(kw[7], kw[1], kw[6] * kw[0]), pf10);
+      pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
-    if (lane == 0) sm[28 + par] = 0.0;
+    if (lane == 0) { sm[40 + par] = 0.0; sm[44 + (smp ^ 1)] = 0.0; }
     if (!gated && isfeat && lane < len) {   // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238)
       double rho = lin;
       if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
       if (rho < 0.0) {
         const double err = rho_reset - rho;
         S.fixadd[par * N + lane] = err * err;
-        sm[28 + par] = 1.0;
+        sm[40 + par] = 1.0;
         rho = rho_reset;
         flag |= FLAG_NEGDEPTH;
       } else if (rho > 1e2) {
         S.fixset[par * N + lane] = 1.0;
-        sm[28 + par] = 1.0;
+        sm[40 + par] = 1.0;
         rho = rho_reset;
       }
       lin = rho;
     }
     if (haslin && !(S.dbg & 2)) *linptr = lin;
-    if (lane == slot_next) {   // prediction for the next measurement from the corrected bearing (registers)
-      double zhat[2], Hb[4];
-      h_feat_fast(qn, prm, zhat, Hb);
-      const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mnext);
-      *reinterpret_cast<double2*>(smw + 2) = make_double2(Hb[0], Hb[1]);
-      *reinterpret_cast<double2*>(smw + 4) = make_double2(Hb[2], Hb[3]);
-      *reinterpret_cast<double2*>(smw + 6) = make_double2(zn.x - zhat[0], zn.y - zhat[1]);
-    }
+    if (lane == slot_next) predict(qn, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     par ^= 1;
     smp ^= 1;
@@ -957,7 +975,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
   S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.X = smem + L.X; S.Y = smem + L.Y;
   S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
-  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT;
+  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.featA = smem + L.featA;
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
@@ -969,7 +987,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
-    if (tid == 0) { S.sm[30] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[28] = 0.0; S.sm[29] = 0.0; }
+    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
       const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];
