@@ -19,9 +19,9 @@ for i in range(N):
 for rep in range(2):
     g.step(sc["u"][rep], sc["dt"], sc["z"][rep], sc["slot"], sc["R"])
 # read the workspace of block 0 through a debug hook: the stamps live at d_ws[0..127]
-ws = np.zeros(192, dtype=np.uint64)
+ws = np.zeros(256, dtype=np.uint64)
 capi.lib().viekf_debug_read_ws.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-capi.check(capi.lib().viekf_debug_read_ws(g._h, C.c_void_p(ws.ctypes.data), 192))
+capi.check(capi.lib().viekf_debug_read_ws(g._h, C.c_void_p(ws.ctypes.data), 256))
 t = ws.astype(np.int64)
 def d(a, b): return int(t[b] - t[a])
 print("common prologue (62->63 incl barrier)", d(62, 63))
@@ -39,4 +39,7 @@ for it in range(4):
 for it in range(4):
     w0 = 80 + 4 * it; q0 = 160 + 4 * it
     print("update %d worker detail: blocks %5d | body cols %5d | body block %5d" % (it, d(w0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, w0 + 2)))
+for w in range(7):
+    q0 = 192 + 4 * w
+    print("update 3 worker wave %d: sweep %5d | extract %5d | B1 wait %5d   (B2-pass skew vs wave 0: %d)" % (w, d(q0, q0 + 1), d(q0 + 1, q0 + 2), d(q0 + 2, q0 + 3), d(192, q0)))
 print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(63, 73))

@@ -24,7 +24,7 @@ namespace viekf {
 constexpr int XK = 38;  // contraction depth of the propagate GEMM: 16 (U) + 16 (Phi_fb) + 6 (Gd)
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, featA, mslot, mz, mR, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, featA, mslot, mseq, mz, mR, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
@@ -46,7 +46,7 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     Pbc = take(nf * 16);
     PhibbT = take(256);
     featA = take(36 * (N > 0 ? N : 1));
-    mslot = take(32); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
+    mslot = take(32); mseq = take(64); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
 };
@@ -271,7 +271,8 @@ constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lis
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
       *xdb, *Pbc, *PhibbT, *Pd, *featA, *mz, *mR;
-  int* mslot;   // [MCAP] slot, or -(code+2) for a measurement that is not run (code -1/2/3 -> -1/-4/-5)
+  int* mslot;   // [MCAP] slot, or -1 for a measurement that is not run
+  int2* mseq;   // [MCAP] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
   int N, n, nf, len, M, mstride, do_prop, b, dbg;
   double* stamps;
@@ -564,7 +565,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       const bool ascol = !asrow && I == slot;   // block (slot, J): its rows 0,1, transposed
       if (vb_[ia] && (asrow || ascol)) {
         const int base = 16 + 3 * (asrow ? I : J);
-        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch)
+        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch;
+        // two separately predicated store groups measured slower)
         const double a0 = pb[ia][0], a1 = asrow ? pb[ia][1] : pb[ia][3];
         const double b0 = asrow ? pb[ia][3] : pb[ia][1], b1 = pb[ia][4];
         const double c0 = asrow ? pb[ia][6] : pb[ia][2], c1 = asrow ? pb[ia][7] : pb[ia][5];
@@ -601,8 +603,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   __syncthreads();  // B1 : the service published the first measurement's {Hb, res, S^-1, verdict}
   int it_ = 0;
   while (m < S.M) {
-    const int mnext = res_next_valid(S, m + 1);
-    const int slot_next = (mnext < S.M) ? S.mslot[mnext] : -1;
+    const int2 sq = S.mseq[m];
+    const int mnext = sq.x, slot_next = sq.y;
     const double* mbx = S.sm + 16 * smp;
     const bool gated = mbx[10] != 0.0;
     // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241)
@@ -620,6 +622,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 0);
     __syncthreads();  // B2 : gain vectors Kt / Wt are in LDS
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
+    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
     const bool run = !gated && S.sm[44 + smp] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     apply_fixes(par ^ 1);
     if (run) {
@@ -693,12 +696,15 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     par ^= 1;
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 2);
+    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 1);
     if (slot_next >= 0) extract_cols(slot_next, pp ^ 1, Ib, Jb, vb);   // reads the swept registers
     // NOTE: a fix_depth edit touches P(rho,rho) only, never the zeta columns just extracted
     pp ^= 1;
     smp ^= 1;
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 3);
+    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
     __syncthreads();  // B1
+    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 3);
     it_++;
     m = mnext;
   }
@@ -847,17 +853,17 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     *reinterpret_cast<double2*>(mb + 8) = make_double2(Si[2], Si[3]);
     mb[10] = (mahal > 9.0) ? 1.0 : 0.0;                                                   // gate (:235-239)
   };
-  if (m < M && lane == S.mslot[m]) {
-    const double q0[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
-    predict(q0, m, 0);
-  }
+  // this lane's quaternion and linear state live in registers for the whole loop (written back once at the end)
+  double qn[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
+  double lin = *linptr;
+  if (m < M && lane == S.mslot[m]) predict(qn, m, 0);
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
   int it_ = 0;
 
   while (m < M) {
-    const int mnext = res_next_valid(S, m + 1);
-    const int slot_next = (mnext < M) ? S.mslot[mnext] : -1;
+    const int2 sq = S.mseq[m];
+    const int mnext = sq.x, slot_next = sq.y;
     const double* Pr = S.Praw + pp * 2 * n;
     const double* mbx = sm + 16 * smp;
     const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2),
@@ -891,8 +897,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const bool corr = !gated && !bad && !(S.dbg & 2);
     // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
     // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
-    double qn[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
-    double lin = *linptr;
     if (corr) {
       double t1[3], t2[3], zt[3], v[3], e[4];
       bearing_frame_fast(qn, t1, t2, zt);
@@ -905,7 +909,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       for (int i = 0; i < 4; i++) { A[i] = isatt ? qn[i] : e[i]; Bq[i] = isatt ? e[i] : qn[i]; }
       q_otimes(A, Bq, qn);
       lin += isfeat ? dv2 : dv0;
-      if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
       // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
       pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
       pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
@@ -930,7 +933,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       }
       lin = rho;
     }
-    if (haslin && !(S.dbg & 2)) *linptr = lin;
     if (lane == slot_next) predict(qn, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     par ^= 1;
@@ -943,6 +945,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     m = mnext;
   }
 
+  if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
+  if (haslin) *linptr = lin;
   RES_STAMP(S, lane == 0, 11);
   __syncthreads();  // B5
   RES_STAMP(S, lane == 0, 12);
@@ -978,6 +982,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.featA = smem + L.featA;
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
+  S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
   S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = do_prop >> 8; S.b = b; S.stamps = a.ws;
 
@@ -1003,6 +1008,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
     }
   }
   RES_STAMP(S, tid == 0, 62);
+  __syncthreads();
+  for (int mm_ = tid; mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= MCAP)
+    int nx = mm_ + 1;
+    while (nx < M && S.mslot[nx] < 0) nx++;
+    S.mseq[mm_] = make_int2(nx, nx < M ? S.mslot[nx] : -1);
+  }
   __syncthreads();
   RES_STAMP(S, tid == 0, 63);
   if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
