@@ -542,8 +542,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 #pragma unroll
   for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tr_, td_, ia, Ib[ia], Jb[ia]);
   // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
-  auto apply_fixes = [&](int mb) {
-    if (S.sm[40 + mb] == 0.0) return;   // nothing posted (the common case): one uniform LDS read
+  auto apply_fixes = [&](int mb, double pending) {
+    if (pending == 0.0) return;   // nothing posted (the common case); the flag word was read ahead of the barrier
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
       const int I = Ib[ia];
@@ -594,7 +594,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia] + 2) = make_double2(pb[ia][3], pb[ia][4]);
     }
   if (m < S.M) {
-    apply_fixes(par ^ 1);
+    apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
     extract_cols(S.mslot[m], 0, Ib, Jb, vb);
     extract_body(S.mslot[m], 0);
   }
@@ -607,6 +607,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const int mnext = sq.x, slot_next = sq.y;
     const double* mbx = S.sm + 16 * smp;
     const bool gated = mbx[10] != 0.0;
+    const double fixpending = S.sm[40 + (par ^ 1)];   // posted before B1 by the service wave: read it ahead of B2
     // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241)
     if (tid < n && !gated) {
       const int irow = tid;
@@ -623,19 +624,20 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     __syncthreads();  // B2 : gain vectors Kt / Wt are in LDS
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
-    const bool run = !gated && S.sm[44 + smp] == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
-    apply_fixes(par ^ 1);
+    const double nanword = S.sm[44 + smp];   // issued first; its latency overlaps the gain-vector loads below
+    const int it = tid;
+    // ---- issue every LDS read of this phase up front (registers are plentiful with symmetric ownership), then compute
+    double2 kI[RB][3], wJ[RB][3];
+#pragma unroll
+    for (int ia = 0; ia < RB; ia++) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * Ib[ia] + r));
+#pragma unroll
+      for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * Jb[ia] + s));
+    }
+    apply_fixes(par ^ 1, fixpending);
+    const bool run = !gated && nanword == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     if (run) {
-      const int it = tid;
-      // ---- issue every LDS read of this phase up front (registers are plentiful with symmetric ownership), then compute
-      double2 kI[RB][3], wJ[RB][3];
-#pragma unroll
-      for (int ia = 0; ia < RB; ia++) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * Ib[ia] + r));
-#pragma unroll
-        for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * Jb[ia] + s));
-      }
       // body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
       // 8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
       const bool hasc = it < 8 * N;
@@ -708,7 +710,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     it_++;
     m = mnext;
   }
-  apply_fixes(par ^ 1);
+  apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
   RES_STAMP(S, tid == 0, 72);
   __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
 
