@@ -141,6 +141,20 @@ int viekf_batch_init_feature(viekf_batch *b, const double *pix /*[batch][2]*/, c
 int viekf_batch_update_feat(viekf_batch *b, const double *z, const int32_t *slot, int32_t M, const double *R,
                             int32_t r_mode, int32_t *result, viekf_mem where);
 
+/* VIEKF::keep_only_features / clear_feature, src/vi_ekf/vi_ekf_feat.cpp:50-73,81-117: every feature f < len with
+ * keep[b][f] == 0 is removed, survivors (state and covariance rows/columns) move up in order, the rest is zeroed.
+ * keep [batch][num_features]; new_len [batch] (may be NULL).  The keyframe-overlap test of keep_only_features
+ * (:119-139) is host bookkeeping and stays with the caller. */
+int viekf_batch_keep_features(viekf_batch *b, const uint8_t *keep, int32_t *new_len, viekf_mem where);
+
+/* Bounded device-side history for delayed measurements (the reference rewinds its 250-deep ring of (x,P,t),
+ * include/vi_ekf.h:50,156-160, src/vi_ekf/vi_ekf_meas.cpp:45-63).  viekf_batch_history_resize allocates `depth`
+ * snapshot slots of the whole batch (depth * batch * (8 n ld + 8 nx) bytes: choose it, the reference's 250 would be
+ * 55 MB per filter at N=50); snapshot copies the live (x, P, len) into a slot, restore copies it back. */
+int viekf_batch_history_resize(viekf_batch *b, int32_t depth);
+int viekf_batch_snapshot(viekf_batch *b, int32_t slot);
+int viekf_batch_restore(viekf_batch *b, int32_t slot);
+
 /* ONE measurement of any model of the reference's table per filter: VIEKF::update with
  * h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, src/vi_ekf/vi_ekf_meas.cpp:196-386.
  * type: viekf_meas_type.  z [batch][zdim] (ATT/QZETA: quaternion, zdim 4).  R: rdim x rdim column-major,

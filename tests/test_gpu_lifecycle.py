@@ -1,0 +1,73 @@
+"""Feature lifecycle and history on the device: keep_only_features / clear_feature compaction
+(reference src/vi_ekf/vi_ekf_feat.cpp:50-117) against the oracle, and the snapshot ring used for rewinds."""
+import numpy as np
+import pytest
+
+import vi_ekf_amd as v
+from oracle import oracle as orc
+from vi_ekf_amd import scene
+from tests.test_gpu_parity import assert_close, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N", [6, 12])
+def test_keep_features_matches_clear_feature(N):
+    B = 3
+    sc = scene.make_scene(B, N, 3, seed=80 + N)
+    g = v.BatchVIEKF(B, N, sc["params"])
+    fs = [orc.OracleFilter(N).init(**oracle_params(sc["params"])) for _ in range(B)]
+    for i in range(N):
+        g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        for b in range(B):
+            fs[b].init_feature(sc["pix"][b, i], i)
+    for s in range(2):
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+        for b in range(B):
+            fs[b].run_steps(sc["u"][s, b][None], sc["dt"][b], sc["z"][s, b][None], sc["slot"][b], sc["R"])
+    keep = np.ones((B, N), dtype=np.uint8)
+    keep[0, [1, 4]] = 0            # drop two in the middle
+    keep[1, N - 1] = 0             # drop the last
+    # filter 2 keeps everything
+    nl = g.keep_features(keep)
+    for b in range(B):
+        for fid in [i for i in range(N) if not keep[b, i]]:
+            fs[b].clear_feature(fid)        # ids == initial slot numbers (init_feature counts from 0)
+    assert (nl == [N - 2, N - 1, N]).all() and (g.get_len_features() == nl).all()
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x after keep_features")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after keep_features")
+    # the compacted filters keep running: re-initialise one feature and do another step on the survivors
+    ok = g.init_feature(sc["pix"][:, 0, :].copy() + 3.0, np.full(B, 4.0))
+    for b in range(B):
+        assert bool(ok[b]) == fs[b].init_feature(sc["pix"][b, 0] + 3.0, 99, 4.0)
+    M = N - 2
+    z = np.ascontiguousarray(sc["z"][2][:, :M, :])
+    slot = np.tile(np.arange(M - 1, -1, -1, dtype=np.int32), (B, 1))
+    res = g.step(sc["u"][2], sc["dt"], z, slot, sc["R"])
+    for b in range(B):
+        ref = fs[b].run_steps(sc["u"][2, b][None], sc["dt"][b], z[b][None], slot[b], sc["R"])[0]
+        assert (res[b] == ref).all()
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x after step on compacted filters")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after step on compacted filters")
+
+
+def test_snapshot_restore_replays_identically():
+    B, N = 4, 12
+    sc = scene.make_scene(B, N, 4, seed=91)
+    g = v.BatchVIEKF(B, N, sc["params"])
+    for i in range(N):
+        g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+    g.history_resize(2)
+    g.step(sc["u"][0], sc["dt"], sc["z"][0], sc["slot"], sc["R"])
+    g.snapshot(1)
+    x1, P1 = g.get_state(), g.get_covariance()
+    for s in (1, 2):
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+    x3, P3 = g.get_state(), g.get_covariance()
+    g.restore(1)                                   # rewind (reference vi_ekf_meas.cpp:45-63) ...
+    assert np.array_equal(g.get_state(), x1) and np.array_equal(g.get_covariance(), P1)
+    for s in (1, 2):                               # ... and replay: bit-identical
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+    assert np.array_equal(g.get_state(), x3) and np.array_equal(g.get_covariance(), P3)
+    with pytest.raises(v.ViekfError):
+        g.snapshot(2)

@@ -221,3 +221,26 @@ def test_device_pointer_path_matches_host_path():
         assert (r2.cpu().numpy() == r1).all()
     assert np.array_equal(g1.get_state(), g2.get_state())
     assert np.array_equal(g1.get_covariance(), g2.get_covariance())
+
+
+@pytest.mark.parametrize("N,M", [(64, 4), (150, 3)])
+def test_wide_p_streaming_family(N, M):
+    """wide covariance (BASELINE config 5: N=150, n=466): the streaming family, a few updates per step"""
+    B, steps = 2, 2
+    sc = scene.make_scene(B, N, steps, seed=300 + N)
+    z = np.ascontiguousarray(sc["z"][:, :, :M, :])
+    slot = np.ascontiguousarray(sc["slot"][:, :M])
+    fs = []
+    for b in range(B):
+        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+        for i in range(N):
+            f.init_feature(sc["pix"][b, i], i)
+        fs.append(f)
+    g = make_gpu(sc, B, N)
+    for s in range(steps):
+        res = g.step(sc["u"][s], sc["dt"], z[s], slot, sc["R"])
+        for b in range(B):
+            ref = fs[b].run_steps(sc["u"][s, b][None], sc["dt"][b], z[s, b][None], slot[b], sc["R"])[0]
+            assert (res[b] == ref).all()
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")

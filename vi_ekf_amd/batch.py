@@ -208,6 +208,24 @@ class BatchVIEKF:
         self._keep = []
         return res
 
+    def keep_features(self, keep):
+        """drop the features with keep[b, f] == 0 and compact (reference vi_ekf_feat.cpp:50-117) -> new len [B]"""
+        self._keep = []
+        pk, w = self._arg(keep, np.uint8, (self.B, self.N), None)
+        nl = np.empty(self.B, dtype=np.int32)
+        capi.check(capi.lib().viekf_batch_keep_features(self._h, pk, C.c_void_p(nl.ctypes.data), capi.HOST))
+        self._keep = []
+        return nl
+
+    def history_resize(self, depth):
+        capi.check(capi.lib().viekf_batch_history_resize(self._h, int(depth)))
+
+    def snapshot(self, slot):
+        capi.check(capi.lib().viekf_batch_snapshot(self._h, int(slot)))
+
+    def restore(self, slot):
+        capi.check(capi.lib().viekf_batch_restore(self._h, int(slot)))
+
     def step(self, u, dt, z, slot, R, result=None):
         """one hot-path step: propagate + M feature updates"""
         self._keep = []

@@ -21,7 +21,8 @@ SYMBOLS = [
     "viekf_batch_create", "viekf_batch_destroy", "viekf_batch_reset", "viekf_batch_dims", "viekf_batch_set_stream",
     "viekf_batch_sync", "viekf_batch_set_kernel", "viekf_batch_get_state", "viekf_batch_set_state",
     "viekf_batch_get_status", "viekf_batch_propagate", "viekf_batch_init_feature", "viekf_batch_update_feat",
-    "viekf_batch_step", "viekf_batch_update",
+    "viekf_batch_step", "viekf_batch_update", "viekf_batch_keep_features", "viekf_batch_history_resize",
+    "viekf_batch_snapshot", "viekf_batch_restore",
 ]
 
 
@@ -114,6 +115,10 @@ def lib():
         L.viekf_batch_init_feature.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_update_feat.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int]
         L.viekf_batch_update.argtypes = [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int]
+        L.viekf_batch_keep_features.argtypes = [_vp, _vp, _vp, C.c_int]
+        L.viekf_batch_history_resize.argtypes = [_vp, C.c_int32]
+        L.viekf_batch_snapshot.argtypes = [_vp, C.c_int32]
+        L.viekf_batch_restore.argtypes = [_vp, C.c_int32]
         L.viekf_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int]
         _lib = L
     return _lib

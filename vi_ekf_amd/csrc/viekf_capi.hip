@@ -53,6 +53,9 @@ struct viekf_batch {
   size_t res_lds = 0;
   DevParams dp;
   DevParams* d_dp = nullptr;
+  int hist_depth = 0;
+  double *h_x = nullptr, *h_P = nullptr;
+  int* h_len = nullptr;
 };
 
 namespace {
@@ -360,7 +363,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp};
+  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -558,6 +561,67 @@ int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
   HIP_TRY(hipMemcpy(out, b->d_ws, (size_t)count * 8, hipMemcpyDeviceToHost));
   return VIEKF_OK;
 }
+
+int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!keep) return fail(VIEKF_ERR_INVALID, "keep must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t BN = (size_t)b->B * b->N;
+  const uint8_t* d_keep = nullptr;
+  int32_t* d_nl = nullptr;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(BN) + stage_size(sizeof(int32_t) * b->B))) return rc;
+  if (int rc = in_ptr(b, keep, BN, where, &d_keep)) return rc;
+  if (new_len) d_nl = where == VIEKF_DEVICE ? new_len : static_cast<int32_t*>(stage_take(b, sizeof(int32_t) * b->B));
+  StreamArgs a = make_args(b);
+  const size_t lds = sizeof(double) * (size_t)b->n + sizeof(int) * (size_t)(b->n + 4);
+  hipLaunchKernelGGL(k_keep_features<kThreads>, dim3(b->B), dim3(kThreads), lds, b->stream, a, d_keep, d_nl);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (new_len) HIP_TRY(hipMemcpyAsync(new_len, d_nl, sizeof(int32_t) * b->B, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
+  if (int rc = check_batch(b)) return rc;
+  if (depth < 0 || depth > 4096) return fail(VIEKF_ERR_INVALID, "0 <= depth <= 4096");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->h_x) { HIP_TRY(hipFree(b->h_x)); b->h_x = nullptr; }
+  if (b->h_P) { HIP_TRY(hipFree(b->h_P)); b->h_P = nullptr; }
+  if (b->h_len) { HIP_TRY(hipFree(b->h_len)); b->h_len = nullptr; }
+  b->hist_depth = 0;
+  if (depth == 0) return VIEKF_OK;
+  HIP_TRY(hipMalloc(&b->h_x, sizeof(double) * (size_t)depth * b->B * b->nxs));
+  HIP_TRY(hipMalloc(&b->h_P, sizeof(double) * (size_t)depth * b->B * b->n * b->ld));
+  HIP_TRY(hipMalloc(&b->h_len, sizeof(int) * (size_t)depth * b->B));
+  b->hist_depth = depth;
+  return VIEKF_OK;
+}
+
+static int history_copy(viekf_batch* b, int32_t slot, bool save) {
+  if (int rc = check_batch(b)) return rc;
+  if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t nx = sizeof(double) * (size_t)b->B * b->nxs, nP = sizeof(double) * (size_t)b->B * b->n * b->ld,
+               nl = sizeof(int) * (size_t)b->B;
+  char *hx = reinterpret_cast<char*>(b->h_x) + nx * slot, *hP = reinterpret_cast<char*>(b->h_P) + nP * slot,
+       *hl = reinterpret_cast<char*>(b->h_len) + nl * slot;
+  if (save) {
+    HIP_TRY(hipMemcpyAsync(hx, b->d_x, nx, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(hP, b->d_P, nP, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(hl, b->d_len, nl, hipMemcpyDeviceToDevice, b->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(b->d_x, hx, nx, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_P, hP, nP, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_len, hl, nl, hipMemcpyDeviceToDevice, b->stream));
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_snapshot(viekf_batch* b, int32_t slot) { return history_copy(b, slot, true); }
+int viekf_batch_restore(viekf_batch* b, int32_t slot) { return history_copy(b, slot, false); }
 
 int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zdim, const double* R, int32_t rdim,
                        int32_t r_mode, const int32_t* slot, const uint8_t* active, int32_t* result, viekf_mem where) {

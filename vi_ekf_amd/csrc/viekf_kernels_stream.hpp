@@ -688,6 +688,55 @@ __global__ __launch_bounds__(T) void k_init_feature(StreamArgs a, const double* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// keep_only_features / clear_feature (vi_ekf_feat.cpp:50-73,81-117): drop the features whose keep flag is 0 and shift the
+// survivors (state and covariance rows/columns) to the upper-left corner, zeroing what is left over.  One workgroup per
+// filter; columns are moved through an LDS buffer in increasing order, so the in-place compaction never overwrites a
+// column that is still needed.  (The keyframe-overlap bookkeeping of keep_only_features stays on the host.)
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_keep_features(StreamArgs a, const unsigned char* __restrict__ keep_all,
+                                                     int* __restrict__ new_len) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, ld = a.ld, N = a.N;
+  double* colbuf = smem;                                   // [n]
+  int* srcrow = reinterpret_cast<int*>(smem + n);          // [n] old row index of new row i (or -1)
+  int* cnt = srcrow + n;
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const int len = a.len[b];
+  const unsigned char* keep = keep_all + (long)b * N;
+  if (tid == 0) {
+    for (int i = 0; i < 16; i++) srcrow[i] = i;
+    int k = 0;
+    for (int f = 0; f < len; f++)
+      if (keep[f]) { for (int q = 0; q < 3; q++) srcrow[16 + 3 * k + q] = 16 + 3 * f + q; k++; }
+    for (int i = 16 + 3 * k; i < n; i++) srcrow[i] = -1;
+    *cnt = k;
+  }
+  __syncthreads();
+  const int k = *cnt;
+  if (k == len) { if (new_len && tid == 0) new_len[b] = len; return; }   // nothing to drop
+  // state: features are 5 doubles each
+  if (tid == 0) {
+    int w = 0;
+    for (int f = 0; f < len; f++)
+      if (keep[f]) { if (w != f) for (int q = 0; q < 5; q++) xg[xZ + 5 * w + q] = xg[xZ + 5 * f + q]; w++; }
+    for (int i = xZ + 5 * k; i < xZ + 5 * len; i++) xg[i] = 0.0;
+  }
+  const int nk = 16 + 3 * k, nold = 16 + 3 * len;
+  for (int jn = 0; jn < nold; jn++) {
+    const int jo = (jn < nk) ? srcrow[jn] : -1;
+    if (jo >= 0) for (int i = tid; i < nk; i += T) colbuf[i] = P[srcrow[i] + (long)jo * ld];
+    __syncthreads();
+    for (int i = tid; i < nold; i += T) P[i + (long)jn * ld] = (jo >= 0 && i < nk) ? colbuf[i] : 0.0;
+    __syncthreads();
+  }
+  if (tid == 0) { a.len[b] = k; if (new_len) new_len[b] = k; }
+}
+
 // fill every filter with the initial state (vi_ekf.cpp:70-81 / :134-144)
 __global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, const double* __restrict__ Pdiag /*n*/) {
   const int b = blockIdx.x;
