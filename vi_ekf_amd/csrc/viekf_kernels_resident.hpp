@@ -51,6 +51,15 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
   }
 };
 
+// 1/d from v_rcp_f64 and two Newton steps (5 instructions; the IEEE division expands to ~14 with a longer dependent chain)
+__device__ __forceinline__ double rcp_fast(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+
 // exp() of a small rotation vector as a quaternion (src/quat.cpp:64-80).  For |v| < 0.5 both
 // cos(h) and sin(h)/(2h), h = |v|/2, are even series in h^2 -- no sqrt, no range reduction; they
 // agree with either branch of the reference (the 1e-4 small-angle branch differs from the exact
@@ -58,7 +67,20 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
 __device__ __forceinline__ void q_exp_fast(const double* v, double* o) {
   const double n2 = dot3(v, v);
   const double h2 = 0.25 * n2;
-  if (h2 < 0.0625) {
+  if (h2 < 2.5e-3) {                              // |v| < 0.1: truncation < 3e-20, the usual size of a filter correction
+    double c = 1.0 / 40320.0;
+    c = fma(c, h2, -1.0 / 720.0);
+    c = fma(c, h2, 1.0 / 24.0);
+    c = fma(c, h2, -0.5);
+    c = fma(c, h2, 1.0);                          // cos(h)
+    double s = 1.0 / 362880.0;
+    s = fma(s, h2, -1.0 / 5040.0);
+    s = fma(s, h2, 1.0 / 120.0);
+    s = fma(s, h2, -1.0 / 6.0);
+    s = fma(s, h2, 1.0);                          // sin(h)/h
+    s *= 0.5;
+    o[0] = c; o[1] = s * v[0]; o[2] = s * v[1]; o[3] = s * v[2];
+  } else if (h2 < 0.0625) {
     double c = -1.0 / 20922789888000.0;          // -1/16!
     c = fma(c, h2, 1.0 / 87178291200.0);          // 1/14!
     c = fma(c, h2, -1.0 / 479001600.0);           // -1/12!
@@ -114,11 +136,26 @@ __device__ __forceinline__ void h_feat_fast(const double* qz, const DevParams& p
   Hb[3] = f1 * (zy * c2[2] - c2[1]);
 }
 
+// The same from an already computed frame of a UNIT bearing quaternion: (t1, t2, zeta) is then orthonormal and right-handed,
+// so zeta x t1 = t2 and zeta x t2 = -t1 (for |q|^2 = 1 + e the shortcut is off by O(e) ~ 1e-15, far inside the parity bar).
+__device__ __forceinline__ void h_feat_frame(const double* t1, const double* t2, const double* z, const DevParams& p,
+                                             double* zhat, double* Hb) {
+  const double iez = rcp_fast(z[2]);
+  const double zx = z[0] * iez, zy = z[1] * iez;
+  zhat[0] = fma(p.focal[0], zx, p.cam_center[0]);
+  zhat[1] = fma(p.focal[1], zy, p.cam_center[1]);
+  const double f0 = p.focal[0] * iez, f1 = p.focal[1] * iez;
+  Hb[0] = f0 * fma(zx, t2[2], -t2[0]);
+  Hb[1] = f0 * fma(-zx, t1[2], t1[0]);
+  Hb[2] = f1 * fma(zy, t2[2], -t2[1]);
+  Hb[3] = f1 * fma(-zy, t1[2], t1[1]);
+}
+
 // 2x2 inverse through the adjugate and ONE reciprocal (the reference's LU form, vi_ekf_meas.cpp:232, differs by
 // rounding only; three dependent fp64 divisions would sit on the per-update critical path)
 __device__ __forceinline__ void inv2_fast(const double* S, double* Si) {
   const double det = S[0] * S[3] - S[1] * S[2];
-  const double r = 1.0 / det;
+  const double r = rcp_fast(det);
   Si[0] = S[3] * r; Si[1] = -S[1] * r; Si[2] = -S[2] * r; Si[3] = S[0] * r;
 }
 
@@ -285,69 +322,16 @@ __device__ __forceinline__ int res_next_valid(const ResShared& S, int from) {
   return m;
 }
 
-template <int RB, int TW>
-__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
-  const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
-  double* P = a.P + (long)S.b * n * ld;
-  // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept, on wrapped diagonals
-  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: rows I >= N/2 of
-  //   it are left unowned).  Thread (tr, td) of a TR x TD grid owns rows I = tr + TR*a (a < RB) of diagonal d = td.
-  const int tr_ = tid % TR, td_ = tid / TR;
+// Propagate set-up shared by the worker layouts (LDS only): Phi_bb, Phi_fb rows, Gd rows, U and V  ->  X, Y, T16, Gdb ...
+// Barriers B1p, B2p, B2q inside; the caller continues with B3p.
+template <int TW>
+__device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResShared& S, int tid) {
+  const int N = S.N, nf = S.nf;
   const DevParams& prm = *a.dp;
-  double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
-  double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
-  // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
-  const bool evenN = (N & 1) == 0;
-  auto blk = [&](int tr, int td, int ia, int& I, int& J) -> bool {   // block ia of thread (tr,td); false = not owned
-    I = tr + TR * ia;
-    const bool v = td < TD && I < N && !(evenN && td == N / 2 && I >= N / 2);
-    I = min(I, N - 1);                    // clamped: every LDS / global read stays in range, results never stored
-    J = I + min(td, TD - 1);
-    if (J >= N) J -= N;
-    return v;
-  };
-
-  double pb[RB][9];   // pb[a][r*3+s] = P[16+3I+r][16+3J+s]
-  {
-    const int tr = opaque(tr_), td = opaque(td_);
-#pragma unroll
-    for (int ia = 0; ia < RB; ia++) {
-      int I, J;
-      blk(tr, td, ia, I, J);
-      const double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);
-#pragma unroll
-      for (int s = 0; s < 3; s++)
-#pragma unroll
-        for (int r = 0; r < 3; r++) pb[ia][r * 3 + s] = pu[r + (long)s * ld];
-    }
-    // body columns -> LDS (coalesced along rows)
-    for (int e = tid; e < nf * 16; e += TW) {
-      const int k = e / nf, row = e - k * nf;
-      Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
-    }
-    for (int e = tid; e < 256; e += TW) Pbb[(e & 15) * 16 + (e >> 4)] = P[(e & 15) + (long)(e >> 4) * ld];
-  }
-
-  // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots), kept in SGPRs
-  double Lff[9];
-  {
-    const double lf[3] = {a.lambda[16], a.lambda[17], a.lambda[18]};
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int s = 0; s < 3; s++) Lff[r * 3 + s] = uniform_f64(prm.use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0);
-  }
-  const double lfe[3] = {uniform_f64(a.lambda[16]), uniform_f64(a.lambda[17]), uniform_f64(a.lambda[18])};
-  const bool partial = prm.use_partial_update != 0;
-  int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
-  RES_STAMP(S, tid == 0, 64);
-  __syncthreads();  // B0
-  RES_STAMP(S, tid == 0, 65);
-
-  if (S.do_prop) {
-    double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
-    double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
-    const double dt = S.sm[42];
+  double* Pbc = S.Pbc; double* Pbb = S.Pbb;
+  double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
+  double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
+  const double dt = S.sm[42];
     __syncthreads();  // B1p : body Jacobian ready (service)
 
     for (int e = tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303)
@@ -439,6 +423,112 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         Y[(3 * I + r) * XK + 16 + k] = sv;   // V
       }
     }
+}
+
+// P+[feature rows, body columns] (in LDS, in place: each output needs only U, already in X) and the body block (-> Mbb)
+template <int TW>
+__device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShared& S, int tid) {
+  const int nf = S.nf;
+  const DevParams& prm = *a.dp;
+  double* Pbc = S.Pbc;
+  double* X = S.X; double* Phibb = S.Phibb; double* Gdb = S.Gdb; double* T16 = S.T16;
+    // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
+#pragma unroll 1
+    for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
+      const int row = e >> 4, k = e & 15;
+      const double* xr = X + row * XK;
+      const double* pt = S.PhibbT + k;          // Phi_bb[k][c] = PhibbT[c*16 + k]: conflict-free across the 16 k-lanes
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const double2 xv = *reinterpret_cast<const double2*>(xr + c);
+        s = fma(xv.x, pt[c * 16], s);
+        s = fma(xv.y, pt[c * 16 + 16], s);
+      }
+      double g = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const double2 xv = *reinterpret_cast<const double2*>(xr + 32 + c);
+        g = fma(xv.x, Gdb[k * 6 + c], g);
+        g = fma(xv.y, Gdb[k * 6 + c + 1], g);
+      }
+      Pbc[e] = s + g;
+    }
+    for (int e = tid; e < 256; e += TW) {
+      const int r = e >> 4, c = e & 15;
+      double s = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
+      double g = 0.0;
+      for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * prm.Qu[k] * Gdb[c * 6 + k];
+      s = s + g;
+      if (r == c) s += a.Qx[r];
+      S.Mbb[e] = s;   // P_bb+ staged in Mbb (T16 / Pbb are still being read by other threads)
+    }
+}
+
+template <int RB, int TW>
+__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
+  const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
+  double* P = a.P + (long)S.b * n * ld;
+  // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept, on wrapped diagonals
+  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: rows I >= N/2 of
+  //   it are left unowned).  Thread (tr, td) of a TR x TD grid owns rows I = tr + TR*a (a < RB) of diagonal d = td.
+  const int tr_ = tid % TR, td_ = tid / TR;
+  const DevParams& prm = *a.dp;
+  double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
+  double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
+  // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
+  const bool evenN = (N & 1) == 0;
+  auto blk = [&](int tr, int td, int ia, int& I, int& J) -> bool {   // block ia of thread (tr,td); false = not owned
+    I = tr + TR * ia;
+    const bool v = td < TD && I < N && !(evenN && td == N / 2 && I >= N / 2);
+    I = min(I, N - 1);                    // clamped: every LDS / global read stays in range, results never stored
+    J = I + min(td, TD - 1);
+    if (J >= N) J -= N;
+    return v;
+  };
+
+  double pb[RB][9];   // pb[a][r*3+s] = P[16+3I+r][16+3J+s]
+  {
+    const int tr = opaque(tr_), td = opaque(td_);
+#pragma unroll
+    for (int ia = 0; ia < RB; ia++) {
+      int I, J;
+      blk(tr, td, ia, I, J);
+      const double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);
+#pragma unroll
+      for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) pb[ia][r * 3 + s] = pu[r + (long)s * ld];
+    }
+    // body columns -> LDS (coalesced along rows)
+    for (int e = tid; e < nf * 16; e += TW) {
+      const int k = e / nf, row = e - k * nf;
+      Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
+    }
+    for (int e = tid; e < 256; e += TW) Pbb[(e & 15) * 16 + (e >> 4)] = P[(e & 15) + (long)(e >> 4) * ld];
+  }
+
+  // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots), kept in SGPRs
+  double Lff[9];
+  {
+    const double lf[3] = {a.lambda[16], a.lambda[17], a.lambda[18]};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int s = 0; s < 3; s++) Lff[r * 3 + s] = uniform_f64(prm.use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0);
+  }
+  const double lfe[3] = {uniform_f64(a.lambda[16]), uniform_f64(a.lambda[17]), uniform_f64(a.lambda[18])};
+  const bool partial = prm.use_partial_update != 0;
+  int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  RES_STAMP(S, tid == 0, 64);
+  __syncthreads();  // B0
+  RES_STAMP(S, tid == 0, 65);
+
+  if (S.do_prop) {
+    double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
+    res_prop_setup<TW>(a, S, tid);
     RES_STAMP(S, tid == 0, 66);
     __syncthreads();  // B3p
     RES_STAMP(S, tid == 0, 67);
@@ -497,39 +587,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       }
     }
     RES_STAMP(S, tid == 0, 69);
-    // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
-#pragma unroll 1
-    for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
-      const int row = e >> 4, k = e & 15;
-      const double* xr = X + row * XK;
-      const double* pt = S.PhibbT + k;          // Phi_bb[k][c] = PhibbT[c*16 + k]: conflict-free across the 16 k-lanes
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        const double2 xv = *reinterpret_cast<const double2*>(xr + c);
-        s = fma(xv.x, pt[c * 16], s);
-        s = fma(xv.y, pt[c * 16 + 16], s);
-      }
-      double g = 0.0;
-#pragma unroll
-      for (int c = 0; c < 6; c += 2) {
-        const double2 xv = *reinterpret_cast<const double2*>(xr + 32 + c);
-        g = fma(xv.x, Gdb[k * 6 + c], g);
-        g = fma(xv.y, Gdb[k * 6 + c + 1], g);
-      }
-      Pbc[e] = s + g;
-    }
-    for (int e = tid; e < 256; e += TW) {
-      const int r = e >> 4, c = e & 15;
-      double s = 0.0;
-#pragma unroll 4
-      for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
-      double g = 0.0;
-      for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * prm.Qu[k] * Gdb[c * 6 + k];
-      s = s + g;
-      if (r == c) s += a.Qx[r];
-      S.Mbb[e] = s;   // P_bb+ staged in Mbb (T16 / Pbb are still being read by other threads)
-    }
+    res_prop_body<TW>(a, S, tid);
     par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
@@ -541,6 +599,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   bool vb[RB];
 #pragma unroll
   for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tr_, td_, ia, Ib[ia], Jb[ia]);
+  const double p0rr = uniform_f64(prm.P0_feat[2]);   // (read here: a global load inside the update loop would put vmcnt waits there)
   // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
   auto apply_fixes = [&](int mb, double pending) {
     if (pending == 0.0) return;   // nothing posted (the common case); the flag word was read ahead of the barrier
@@ -550,7 +609,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       if (vb[ia] && td_ == 0 && I < len) {
         const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
         if (ad != 0.0) { pb[ia][8] += ad; S.fixadd[mb * N + I] = 0.0; }
-        if (st != 0.0) { pb[ia][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
+        if (st != 0.0) { pb[ia][8] = p0rr; S.fixset[mb * N + I] = 0.0; }
       }
     }
   };
@@ -602,61 +661,67 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   __syncthreads();  // Bp
   __syncthreads();  // B1 : the service published the first measurement's {Hb, res, S^-1, verdict}
   int it_ = 0;
+  int2 sq = S.mseq[min(m, MCAP - 1)];
+  const int irow = min(tid, n - 1);
+  const double* kP = S.Kt;
+  const double* wP = S.Wt;
   while (m < S.M) {
-    const int2 sq = S.mseq[m];
     const int mnext = sq.x, slot_next = sq.y;
     const double* mbx = S.sm + 16 * smp;
-    const bool gated = mbx[10] != 0.0;
+    // every LDS read of the gain phase is issued up front and unconditionally (one latency, not a chain of dependent ones)
+    const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2);
+    const double2 sA = *reinterpret_cast<const double2*>(mbx + 6), sB = *reinterpret_cast<const double2*>(mbx + 8);
+    const double2 pr = *reinterpret_cast<const double2*>(S.Praw + pp * 2 * n + 2 * irow);
+    const double gflag = mbx[10];
     const double fixpending = S.sm[40 + (par ^ 1)];   // posted before B1 by the service wave: read it ahead of B2
+    sq = S.mseq[min(mnext, MCAP - 1)];                 // next iteration's table entry (static data)
     // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241)
+    const double w0 = pr.x * hA.x + pr.y * hA.y, w1 = pr.x * hB.x + pr.y * hB.y;
+    const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
+    const bool gated = gflag != 0.0;
     if (tid < n && !gated) {
-      const int irow = tid;
-      const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2);
-      const double2 sA = *reinterpret_cast<const double2*>(mbx + 6), sB = *reinterpret_cast<const double2*>(mbx + 8);
-      const double2 pr = *reinterpret_cast<const double2*>(S.Praw + pp * 2 * n + 2 * irow);
-      const double w0 = pr.x * hA.x + pr.y * hA.y, w1 = pr.x * hB.x + pr.y * hB.y;
-      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
       *reinterpret_cast<double2*>(S.Wt + 2 * irow) = make_double2(w0, w1);
       *reinterpret_cast<double2*>(S.Kt + 2 * irow) = make_double2(k0, k1);
-      if (k0 != k0 || k1 != k1 || hA.x != hA.x || hA.y != hA.y || hB.x != hB.x || hB.y != hB.y) S.sm[44 + smp] = 1.0;
+      // a NaN in H makes every K row NaN (0 * NaN = NaN), so testing K covers the reference's H test (:247) as well
+      if (k0 != k0 || k1 != k1) S.sm[44 + smp] = 1.0;
     }
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 0);
     __syncthreads();  // B2 : gain vectors Kt / Wt are in LDS
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
-    const double nanword = S.sm[44 + smp];   // issued first; its latency overlaps the gain-vector loads below
+    const bool nan = S.sm[44 + smp] != 0.0;
     const int it = tid;
     // ---- issue every LDS read of this phase up front (registers are plentiful with symmetric ownership), then compute
     double2 kI[RB][3], wJ[RB][3];
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
 #pragma unroll
-      for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * Ib[ia] + r));
+      for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * Ib[ia] + r));
 #pragma unroll
-      for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(S.Wt + 2 * (16 + 3 * Jb[ia] + s));
+      for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(wP + 2 * (16 + 3 * Jb[ia] + s));
     }
     apply_fixes(par ^ 1, fixpending);
-    const bool run = !gated && nanword == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
+    const bool run = !gated && !nan && !(S.dbg & 1);   // not gated, no NaN guard
     if (run) {
       // body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
       // 8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
       const bool hasc = it < 8 * N;
       const int g = min(it >> 3, N - 1), j2 = (it & 7) * 2;
-      const double2 cw0 = *reinterpret_cast<const double2*>(S.Wt + 2 * j2);
-      const double2 cw1 = *reinterpret_cast<const double2*>(S.Wt + 2 * j2 + 2);
+      const double2 cw0 = *reinterpret_cast<const double2*>(wP + 2 * j2);
+      const double2 cw1 = *reinterpret_cast<const double2*>(wP + 2 * j2 + 2);
       const double2 clk = *reinterpret_cast<const double2*>(S.lam + j2);
       double2 cki[3], cpv[3];
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-        cki[q] = *reinterpret_cast<const double2*>(S.Kt + 2 * (16 + 3 * g + q));
+        cki[q] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * g + q));
         cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
       }
       // body block: 2 adjacent elements per thread, on the top 128 threads
       const int ib = it - (TW - 128);
       const int br = max(ib, 0) >> 3, bc2 = (max(ib, 0) & 7) * 2;
-      const double2 bkr = *reinterpret_cast<const double2*>(S.Kt + 2 * br);
-      const double2 bw0 = *reinterpret_cast<const double2*>(S.Wt + 2 * bc2);
-      const double2 bw1 = *reinterpret_cast<const double2*>(S.Wt + 2 * bc2 + 2);
+      const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
+      const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
+      const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
       const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
       const double blr = S.lam[br];
       double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
@@ -762,20 +827,27 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // the per-update critical path runs on this wave: let it win the issue arbitration against its SIMD-mate worker wave
   __builtin_amdgcn_s_setprio(3);
   RES_STAMP(S, lane == 0, 0);
-  __syncthreads();  // B0
-  RES_STAMP(S, lane == 0, 1);
-
+  // The dynamics of the propagate need only the state (in LDS since the prologue): they run BEFORE B0, while the worker
+  // waves are still loading P from HBM, instead of holding every worker up afterwards.
+  const double dt = sm[42];
   if (S.do_prop) {
-    const double dt = sm[42];
     for (int i = lane; i < 256; i += 64) S.Abb[i] = 0.0;
     for (int i = lane; i < 96; i += 64) S.Gb[i] = 0.0;
     if (lane < 16) S.xdb[lane] = 0.0;
     if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
     RES_STAMP(S, lane == 0, 2);
-    __syncthreads();  // B1p
-    RES_STAMP(S, lane == 0, 3);
+    // (same wave: the LDS accesses of lane 0 above are complete before the feature lanes read ctx)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, S.featA, S.phiff);
     RES_STAMP(S, lane == 0, 4);
+  }
+  __syncthreads();  // B0
+  RES_STAMP(S, lane == 0, 1);
+
+  if (S.do_prop) {
+    __syncthreads();  // B1p
+    RES_STAMP(S, lane == 0, 3);
     __syncthreads();  // B2p
     __syncthreads();  // B2q (workers expand featA into the Phi_fb rows)
     RES_STAMP(S, lane == 0, 5);
@@ -833,9 +905,9 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   double pf00 = 0.0, pf01 = 0.0, pf10 = 0.0, pf11 = 0.0;
   if (isfeat) { const double* pd = S.Pd + 4 * lane; pf00 = pd[0]; pf01 = pd[1]; pf10 = pd[2]; pf11 = pd[3]; }
   // prediction + innovation of measurement mm (slot == this lane's feature) into mailbox half `hh`, from registers
-  auto predict = [&](const double* qf, int mm, int hh) {
+  auto predict = [&](const double* t1, const double* t2, const double* zt, int mm, int hh) {
     double zhat[2], Hb[4], Sm[4], Si[4];
-    h_feat_fast(qf, prm, zhat, Hb);
+    h_feat_frame(t1, t2, zt, prm, zhat, Hb);
     const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mm);
     const double* R = S.mR + 4 * mm;
     const double r0 = zn.x - zhat[0], r1 = zn.y - zhat[1];
@@ -858,28 +930,34 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // this lane's quaternion and linear state live in registers for the whole loop (written back once at the end)
   double qn[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
   double lin = *linptr;
-  if (m < M && lane == S.mslot[m]) predict(qn, m, 0);
+  // the bearing frame of the CURRENT quaternion is kept alongside it: the prediction after a correction and the next
+  // correction's T_zeta both use it, so it is computed once per update
+  double f1[3], f2[3], fz[3];
+  bearing_frame_fast(qn, f1, f2, fz);
+  const double sgn = isatt ? -1.0 : 1.0;   // q (x) e instead of e (x) q flips the cross term only
+  if (m < M && lane == S.mslot[m]) predict(f1, f2, fz, m, 0);
+  int2 sq = S.mseq[min(m, MCAP - 1)];
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
   int it_ = 0;
 
   while (m < M) {
-    const int2 sq = S.mseq[m];
     const int mnext = sq.x, slot_next = sq.y;
     const double* Pr = S.Praw + pp * 2 * n;
     const double* mbx = sm + 16 * smp;
     const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2),
                   rr = *reinterpret_cast<const double2*>(mbx + 4), sA = *reinterpret_cast<const double2*>(mbx + 6),
                   sB = *reinterpret_cast<const double2*>(mbx + 8);
-    const bool gated = mbx[10] != 0.0;
+    const double gflag = mbx[10];
     const double2 p0 = *reinterpret_cast<const double2*>(Pr + 2 * rid0), p1 = *reinterpret_cast<const double2*>(Pr + 2 * rid1),
                   p2 = *reinterpret_cast<const double2*>(Pr + 2 * rid2);
+    sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
+    const bool gated = gflag != 0.0;
     const double h00 = hA.x, h01 = hA.y, h10 = hB.x, h11 = hB.y, r0 = rr.x, r1 = rr.y;
     const double Si[4] = {sA.x, sA.y, sB.x, sB.y};
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
-    __syncthreads();  // B2 : (the workers wrote the gain rows Kt / Wt; this wave only passes through)
-    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
-    // ---- this lane's gain rows (registers only) and correction lambda o (K r)   (vi_ekf_meas.cpp:241-255)
+    // ---- this lane's gain rows (registers only) and correction lambda o (K r)   (vi_ekf_meas.cpp:241-255): they need only
+    //      the raw columns and this wave's own mailbox, so they run while the worker waves form Kt / Wt
     double dv0, dv1, dv2;
     double kw[8];   // rows 0,1 of this lane: (w0,w1,k0,k1) each -- for the lane's own P_zz update
     int bad = 0;
@@ -895,21 +973,28 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
       bad = __any(bad);   // the 64 lanes together cover every row of K
     }
+    // rotation vector of the correction: bearing  T_zeta [d0 d1],  attitude  [d0 d1 d2]
+    double v[3];
+    v[0] = isatt ? dv0 : (f1[0] * dv0 + f2[0] * dv1);
+    v[1] = isatt ? dv1 : (f1[1] * dv0 + f2[1] * dv1);
+    v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
+    __syncthreads();  // B2 : (the workers wrote the gain rows Kt / Wt; this wave only passes through)
+    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
     const bool corr = !gated && !bad && !(S.dbg & 2);
     // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
     // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
     if (corr) {
-      double t1[3], t2[3], zt[3], v[3], e[4];
-      bearing_frame_fast(qn, t1, t2, zt);
-      v[0] = isatt ? dv0 : (t1[0] * dv0 + t2[0] * dv1);
-      v[1] = isatt ? dv1 : (t1[1] * dv0 + t2[1] * dv1);
-      v[2] = isatt ? dv2 : (t1[2] * dv0 + t2[2] * dv1);
+      double e[4];
       q_exp_fast(v, e);
-      double A[4], Bq[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) { A[i] = isatt ? qn[i] : e[i]; Bq[i] = isatt ? e[i] : qn[i]; }
-      q_otimes(A, Bq, qn);
+      // e (x) q  and  q (x) e  share every term but the sign of the cross product (src/quat.cpp:304-312)
+      const double ex = sgn * e[1], ey = sgn * e[2], ez = sgn * e[3];
+      const double o0 = e[0] * qn[0] - e[1] * qn[1] - e[2] * qn[2] - e[3] * qn[3];
+      const double o1 = e[0] * qn[1] + qn[0] * e[1] + (ey * qn[3] - ez * qn[2]);
+      const double o2 = e[0] * qn[2] + qn[0] * e[2] + (ez * qn[1] - ex * qn[3]);
+      const double o3 = e[0] * qn[3] + qn[0] * e[3] + (ex * qn[2] - ey * qn[1]);
+      qn[0] = o0; qn[1] = o1; qn[2] = o2; qn[3] = o3;
+      bearing_frame_fast(qn, f1, f2, fz);
       lin += isfeat ? dv2 : dv0;
       // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
       pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
@@ -935,7 +1020,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       }
       lin = rho;
     }
-    if (lane == slot_next) predict(qn, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
+    if (lane == slot_next) predict(f1, f2, fz, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     par ^= 1;
     smp ^= 1;
@@ -964,20 +1049,16 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   RES_STAMP(S, lane == 0, 13);
 }
 
-template <int RB, int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
-                                                                const double* __restrict__ u_all,
-                                                                const double* __restrict__ dt_all,
-                                                                const double* __restrict__ z_all,
-                                                                const int* __restrict__ slot_all, int M, int m_stride,
-                                                                const double* __restrict__ R_all, long r_stride_b,
-                                                                long r_stride_m, int* __restrict__ result_all) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int T = (NW + 1) * 64, TW = NW * 64;
+// Common prologue of the fused-step kernels: LDS carve-up, state, lambdas, mailboxes and the measurement table (validity
+// decided once, here).  T = workgroup size.  Ends with the table barriers.
+template <int T>
+__device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, double* smem, int do_prop,
+                                             const double* __restrict__ dt_all, const double* __restrict__ z_all,
+                                             const int* __restrict__ slot_all, int M, int m_stride,
+                                             const double* __restrict__ R_all, long r_stride_b, long r_stride_m,
+                                             int* __restrict__ result_all) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (b >= a.B) return;
   const ResLds L(a.N, a.n, a.nxs);
-  ResShared S;
   S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
   S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.X = smem + L.X; S.Y = smem + L.Y;
   S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
@@ -987,8 +1068,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
   S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = do_prop >> 8; S.b = b; S.stamps = a.ws;
-
-  // ---- common prologue: state, lambdas, mailboxes, measurement table (validity decided once, here)
   {
     const double* xg = a.x + (long)b * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
@@ -1018,6 +1097,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   }
   __syncthreads();
   RES_STAMP(S, tid == 0, 63);
+}
+
+template <int RB, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
+                                                                const double* __restrict__ u_all,
+                                                                const double* __restrict__ dt_all,
+                                                                const double* __restrict__ z_all,
+                                                                const int* __restrict__ slot_all, int M, int m_stride,
+                                                                const double* __restrict__ R_all, long r_stride_b,
+                                                                long r_stride_m, int* __restrict__ result_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int T = (NW + 1) * 64, TW = NW * 64;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.B) return;
+  ResShared S;
+  res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
   if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
   else res_worker<RB, TW>(a, S, TR, TD, tid);
 }
