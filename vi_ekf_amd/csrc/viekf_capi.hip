@@ -13,7 +13,6 @@
 #include "../../include/viekf.h"
 #include "viekf_host.hpp"
 #include "viekf_kernels_resident.hpp"
-#include "viekf_kernels_tile.hpp"
 
 using namespace viekf;
 
@@ -53,8 +52,6 @@ struct viekf_batch {
   int res_inst = -1;    // resident instance index (-1: N not covered by the resident family)
   int res_TR = 0, res_TC = 0;
   size_t res_lds = 0;
-  int2* d_tiles = nullptr;   // tile worker layout: (A, C) of every worker thread's 2x3 block tile
-  int ntiles = 0;
   DevParams dp;
   DevParams* d_dp = nullptr;
   int hist_depth = 0;
@@ -71,7 +68,6 @@ StreamArgs make_args(const viekf_batch* b) {
   a.B = b->B; a.N = b->N; a.nx = b->nx; a.nxs = b->nxs; a.n = b->n; a.ld = b->ld;
   a.ws_stride = b->ws_stride;
   a.dp = b->d_dp;
-  a.tiles = b->d_tiles; a.ntiles = b->ntiles;
   return a;
 }
 
@@ -141,13 +137,11 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   return VIEKF_OK;
 }
 
-// Fused-step ("resident") instances.  kind 0: wrapped-diagonal layout <RB, NW> (viekf_kernels_resident.hpp), worker grid
-// TR = ceil(N/RB) block rows x TD = N/2 + 1 diagonals must fit NW*64 threads.  kind 1: 2x3 block tiles on TILE_NW worker
-// waves (viekf_kernels_tile.hpp).  The first instance that covers N wins; VIEKF_RES_KIND=0/1 forces a kind (experiments).
-struct ResInst { int kind, RB, NW, nmin, nmax; };
+// Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the worker thread
+// grid is TR = ceil(N/RB) block-rows x TD = N/2 + 1 wrapped diagonals and must fit NW*64 threads.
+struct ResInst { int RB, NW, nmin, nmax; };
 const ResInst kResInst[] = {
-    {0, 3, 7, 1, 50},
-    {1, 0, TILE_NW, 2, 50},   // (experimental: measured slower than kind 0 at N = 50; reachable through VIEKF_RES_KIND=1)
+    {3, 7, 1, 50},
 };
 
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
@@ -155,50 +149,23 @@ typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const dou
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
     case 0: return k_step_resident<3, 7>;
-    case 1: return k_step_tile;
   }
   return nullptr;
 }
 
-// tiles (A, C): feature rows {2A, 2A+1} x feature columns {3C, 3C+1, 3C+2} that contain at least one block with I <= J;
-// column-major order, so the threads that share a column triple (and one that share a row pair) sit in few waves
-std::vector<int2> make_tiles(int N) {
-  std::vector<int2> t;
-  const int NA = (N + 1) / 2, NC = (N + 2) / 3;
-  for (int C = 0; C < NC; C++)
-    for (int A = 0; A < NA; A++)
-      if (2 * A <= 3 * C + 2) t.push_back(make_int2(A, C));
-  return t;
-}
-
 int setup_resident(viekf_batch* b) {
   b->res_inst = -1;
-  const char* force = getenv("VIEKF_RES_KIND");
   for (int i = 0; i < (int)(sizeof(kResInst) / sizeof(kResInst[0])); i++) {
     const ResInst& r = kResInst[i];
-    if (force && atoi(force) != r.kind) continue;
-    if (!force && (b->N < r.nmin || b->N > r.nmax)) continue;
-    if (b->N < 1 || b->N > 50) continue;
-    int TR = 0, TC = 0;
-    std::vector<int2> tiles;
-    if (r.kind == 0) {
-      TR = (b->N + r.RB - 1) / r.RB; TC = b->N / 2 + 1;   // TC holds TD, the number of wrapped diagonals
-      if (TR * TC > r.NW * 64) continue;
-    } else {
-      tiles = make_tiles(b->N);
-      if ((int)tiles.size() > r.NW * 64 || b->n > r.NW * 64 || 4 * ((b->n + 2) / 3) > r.NW * 64) continue;
-    }
+    if (b->N < r.nmin || b->N > r.nmax) continue;
+    const int TR = (b->N + r.RB - 1) / r.RB, TC = b->N / 2 + 1;   // TC holds TD, the number of wrapped diagonals
+    if (TR * TC > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > 160 * 1024) continue;
+    if (L.Pbb - L.X < 4 * b->n) continue;   // the second gain-row buffer lives in the propagate-only scratch starting at X
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (r.kind == 1) {
-      if (b->d_tiles) { HIP_TRY(hipFree(b->d_tiles)); b->d_tiles = nullptr; }
-      HIP_TRY(hipMalloc(&b->d_tiles, tiles.size() * sizeof(int2)));
-      HIP_TRY(hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-      b->ntiles = (int)tiles.size();
-    }
     b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
     break;
   }
@@ -398,7 +365,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_tiles};
+  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);

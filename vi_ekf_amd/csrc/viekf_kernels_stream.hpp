@@ -25,8 +25,6 @@ struct StreamArgs {
   int B, N, nx, nxs, n, ld;
   long ws_stride;
   const DevParams* dp;  // device memory (uniform loads); NOT by value: indexing a by-value kernarg array spills it to scratch
-  const int2* tiles;    // tile worker layout (viekf_kernels_tile.hpp): (A, C) per worker thread, [ntiles]
-  int ntiles;
 };
 
 // workspace carve-up (doubles) for one filter
