@@ -282,6 +282,14 @@ __device__ RES_INLINE void res_body_update(double* xs, const double* Kt, const d
 // ------------------------------------------------------------------------------------------------
 // Returns v unchanged but opaque to the optimiser: values derived from it cannot be hoisted out of a loop and kept
 // (or spilled) across iterations; recomputing a few integer ops per use is far cheaper than a scratch round trip.
+// Orders LDS accesses of DIFFERENT lanes of one wave: a store under a lane predicate followed by loads on other lanes.  The
+// hardware executes one wave's LDS instructions in order, but lanes are separate threads to the compiler, which otherwise
+// hoists the other lanes' loads above the predicated store.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-uniform double into SGPRs
   const unsigned long long u = __double_as_longlong(v);
@@ -304,6 +312,7 @@ __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-unif
 #endif
 
 constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lists)
+typedef __attribute__((address_space(3))) volatile int lds_vint_t;
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
@@ -613,19 +622,19 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       }
     }
   };
-  // writes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into the Praw
-  // buffer `buf`: the pair {I, slot} is held either as block (I, slot) or, transposed, as block (slot, J = I)
-  auto extract_cols = [&](int slot, int buf, const int* Ib_, const int* Jb_, const bool* vb_) {
-    double* Pw = S.Praw + buf * 2 * n;
+  // Publishes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into Praw for the
+  // service wave, which turns them into the gain rows: the pair {I, slot} is held either as block (I, slot) (its columns
+  // 0,1) or, transposed, as block (slot, J = I) (its rows 0,1).
+  auto extract_cols = [&](int slot) {
+    double* Pw = S.Praw;
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
-      const int I = Ib_[ia], J = Jb_[ia];
+      const int I = Ib[ia], J = Jb[ia];
       const bool asrow = J == slot;             // block (I, slot): its columns 0,1 are the wanted column pair
       const bool ascol = !asrow && I == slot;   // block (slot, J): its rows 0,1, transposed
-      if (vb_[ia] && (asrow || ascol)) {
+      if (vb[ia] && (asrow || ascol)) {
         const int base = 16 + 3 * (asrow ? I : J);
-        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch;
-        // two separately predicated store groups measured slower)
+        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch)
         const double a0 = pb[ia][0], a1 = asrow ? pb[ia][1] : pb[ia][3];
         const double b0 = asrow ? pb[ia][3] : pb[ia][1], b1 = pb[ia][4];
         const double c0 = asrow ? pb[ia][6] : pb[ia][2], c1 = asrow ? pb[ia][7] : pb[ia][5];
@@ -635,15 +644,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       }
     }
   };
-  // body rows of those columns = rows 3 slot, 3 slot + 1 of the LDS-resident body columns (symmetry)
-  auto extract_body = [&](int slot, int buf) {
-    double* Pw = S.Praw + buf * 2 * n;
-    const int e = opaque(tid);
-    if (e < 32) Pw[2 * (e & 15) + (e >> 4)] = Pbc[(3 * slot + (e >> 4)) * 16 + (e & 15)];
-  };
 
   // ---------------- M sequential feature updates: covariance side ----------------
-  int smp = 0, pp = 0;
   int m = res_next_valid(S, 0);
   // hand the zeta-zeta 2x2 of every diagonal block to the service lanes (they keep it current from here on)
 #pragma unroll
@@ -652,46 +654,53 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia]) = make_double2(pb[ia][0], pb[ia][1]);
       *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia] + 2) = make_double2(pb[ia][3], pb[ia][4]);
     }
+  // body-column item of this thread (constant): feature ig, body columns ij, ij+1
+  const bool ihas = tid < 8 * N;
+  const int ig = min(tid >> 3, N - 1), ij = (tid & 7) * 2;
+  double* stash = S.Praw + 2 * n;   // [2][16][2]: rows j0, j0+1 x body columns of a LATER measurement's feature (see below)
+  int2 sq = S.mseq[min(m, MCAP - 1)];
   if (m < S.M) {
     apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
-    extract_cols(S.mslot[m], 0, Ib, Jb, vb);
-    extract_body(S.mslot[m], 0);
+    const int s0 = S.mslot[m];
+    extract_cols(s0);
+    if (ihas && ig == s0) {   // body rows of the first measurement's columns (P[k][j0+c] = P[j0+c][k])
+      const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * s0) * 16 + ij);
+      const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * s0 + 1) * 16 + ij);
+      *reinterpret_cast<double2*>(S.Praw + 2 * ij) = make_double2(q0.x, q1.x);
+      *reinterpret_cast<double2*>(S.Praw + 2 * ij + 2) = make_double2(q0.y, q1.y);
+    }
+    if (ihas && ig == sq.y) {   // ... and the same rows of the SECOND measurement's feature, for the service wave (phase 0)
+      const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * ig) * 16 + ij);
+      const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * ig + 1) * 16 + ij);
+      *reinterpret_cast<double2*>(stash + 32 + 2 * ij) = make_double2(q0.x, q1.x);
+      *reinterpret_cast<double2*>(stash + 32 + 2 * ij + 2) = make_double2(q0.y, q1.y);
+    }
   }
   RES_STAMP(S, tid == 0, 71);
-  __syncthreads();  // Bp
-  __syncthreads();  // B1 : the service published the first measurement's {Hb, res, S^-1, verdict}
+  __syncthreads();  // Bp : Pd and the first measurement's raw columns are published
+  __syncthreads();  // B1 : the service formed the first measurement's gain rows Kt / Wt, verdict and NaN word
   int it_ = 0;
-  int2 sq = S.mseq[min(m, MCAP - 1)];
-  const int irow = min(tid, n - 1);
-  const double* kP = S.Kt;
-  const double* wP = S.Wt;
+  int cnt = 0;
+  // ONE barrier per update.  Inside a phase the worker waves (1) sweep their blocks with the gains of measurement m,
+  // (2) publish the next measurement's raw feature rows from the swept registers and count themselves in, (3) sweep the
+  // LDS-resident body columns.  The service wave runs the state chain of measurement m meanwhile, then -- once every
+  // worker wave is counted in -- turns the raw columns into the gain rows of measurement m+1, overlapping (3).  The raw BODY
+  // rows are not taken from (3) (that would put it before the count): the owner of the body-column item of the feature
+  // measured two phases later stashes its two rows, and the service applies the one intervening rank-2 update to them.
   while (m < S.M) {
     const int mnext = sq.x, slot_next = sq.y;
-    const double* mbx = S.sm + 16 * smp;
-    // every LDS read of the gain phase is issued up front and unconditionally (one latency, not a chain of dependent ones)
-    const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2);
-    const double2 sA = *reinterpret_cast<const double2*>(mbx + 6), sB = *reinterpret_cast<const double2*>(mbx + 8);
-    const double2 pr = *reinterpret_cast<const double2*>(S.Praw + pp * 2 * n + 2 * irow);
-    const double gflag = mbx[10];
-    const double fixpending = S.sm[40 + (par ^ 1)];   // posted before B1 by the service wave: read it ahead of B2
+    // gain rows {K [n][2], W [n][2]} are double-buffered: the service wave forms those of measurement m+1 while step (3) of
+    // this phase still reads those of measurement m.  The second buffer is the X region (free outside the propagate).
+    const double* kP = (cnt & 1) ? S.X : S.Kt;
+    const double* wP = kP + 2 * n;
+    __builtin_amdgcn_s_setprio(1);   // steps (1)-(2) are on the update's critical path, (3) is not
+    const double fixpending = S.sm[40 + (par ^ 1)];   // posted before the barrier by the service wave
+    const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
+    const double nanw = S.sm[44 + cnt % 3];
     sq = S.mseq[min(mnext, MCAP - 1)];                 // next iteration's table entry (static data)
-    // gain row i = tid:  W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241)
-    const double w0 = pr.x * hA.x + pr.y * hA.y, w1 = pr.x * hB.x + pr.y * hB.y;
-    const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
-    const bool gated = gflag != 0.0;
-    if (tid < n && !gated) {
-      *reinterpret_cast<double2*>(S.Wt + 2 * irow) = make_double2(w0, w1);
-      *reinterpret_cast<double2*>(S.Kt + 2 * irow) = make_double2(k0, k1);
-      // a NaN in H makes every K row NaN (0 * NaN = NaN), so testing K covers the reference's H test (:247) as well
-      if (k0 != k0 || k1 != k1) S.sm[44 + smp] = 1.0;
-    }
-    RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 0);
-    __syncthreads();  // B2 : gain vectors Kt / Wt are in LDS
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
-    const bool nan = S.sm[44 + smp] != 0.0;
     const int it = tid;
-    // ---- issue every LDS read of this phase up front (registers are plentiful with symmetric ownership), then compute
     double2 kI[RB][3], wJ[RB][3];
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
@@ -701,32 +710,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(wP + 2 * (16 + 3 * Jb[ia] + s));
     }
     apply_fixes(par ^ 1, fixpending);
-    const bool run = !gated && !nan && !(S.dbg & 1);   // not gated, no NaN guard
+    const bool gated = gflag != 0.0;
+    const bool run = !gated && nanw == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     if (run) {
-      // body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
-      // 8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
-      const bool hasc = it < 8 * N;
-      const int g = min(it >> 3, N - 1), j2 = (it & 7) * 2;
-      const double2 cw0 = *reinterpret_cast<const double2*>(wP + 2 * j2);
-      const double2 cw1 = *reinterpret_cast<const double2*>(wP + 2 * j2 + 2);
-      const double2 clk = *reinterpret_cast<const double2*>(S.lam + j2);
-      double2 cki[3], cpv[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        cki[q] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * g + q));
-        cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
-      }
-      // body block: 2 adjacent elements per thread, on the top 128 threads
-      const int ib = it - (TW - 128);
-      const int br = max(ib, 0) >> 3, bc2 = (max(ib, 0) & 7) * 2;
-      const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
-      const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
-      const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
-      const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
-      const double blr = S.lam[br];
-      double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
-
-      // ---- feature/feature blocks (registers)
+      // ---- (1) feature/feature blocks (registers)
 #pragma unroll
       for (int ia = 0; ia < RB; ia++)
 #pragma unroll
@@ -736,11 +723,40 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
             const double t = fma(kI[ia][r].y, wJ[ia][s].y, kI[ia][r].x * wJ[ia][s].x);
             pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
           }
-      RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
-      // ---- body columns
-      {
-        double* Pn = S.Praw + (pp ^ 1) * 2 * n;
-        const bool pubg = hasc && g == slot_next;
+    }
+    RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
+    // ---- (2) the NEXT measurement's raw feature rows (a fix_depth edit touches P(rho,rho) only, never these columns)
+    if (slot_next >= 0 && !(S.dbg & 4)) extract_cols(slot_next);
+    asm volatile("" ::: "memory");   // (LDS executes a wave's accesses in order: the count lands after the stores above)
+    if ((tid & 63) == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(S.sm + 49), 1, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
+    RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (3) body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
+    //      8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
+    {
+      const bool hasc = ihas;
+      const int g = ig, j2 = ij;
+      double2 cpv[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
+      if (run) {
+        const double2 cw0 = *reinterpret_cast<const double2*>(wP + 2 * j2);
+        const double2 cw1 = *reinterpret_cast<const double2*>(wP + 2 * j2 + 2);
+        const double2 clk = *reinterpret_cast<const double2*>(S.lam + j2);
+        double2 cki[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) cki[q] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * g + q));
+        // body block: 2 adjacent elements per thread, on the top 128 threads
+        const int ib = it - (TW - 128);
+        const int br = max(ib, 0) >> 3, bc2 = (max(ib, 0) & 7) * 2;
+        const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
+        const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
+        const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
+        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
+        const double blr = S.lam[br];
+        double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           const double L0 = partial ? (clk.x + lfe[q] - lfe[q] * clk.x) : 1.0;
@@ -748,9 +764,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
           cpv[q].x = fma(-L0, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
           cpv[q].y = fma(-L1, fma(cki[q].y, cw1.y, cki[q].x * cw1.x), cpv[q].y);
           if (hasc) *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
-          if (pubg && q < 2) { Pn[2 * j2 + q] = cpv[q].x; Pn[2 * (j2 + 1) + q] = cpv[q].y; }   // next measurement's body rows
         }
-        RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
         if (ib >= 0) {
           const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
           bpv.x = fma(-L0, fma(bkr.y, bw0.y, bkr.x * bw0.x), bpv.x);
@@ -758,19 +772,19 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
           *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
         }
       }
-    } else if (slot_next >= 0) {
-      extract_body(slot_next, pp ^ 1);   // nothing was swept: the body columns are unchanged
+      // rows j0, j0+1 of the feature measured two phases from now, as they stand after this phase's sweep
+      if (hasc && g == sq.y) {
+        double* st = stash + 32 * (cnt & 1) + 2 * j2;
+        *reinterpret_cast<double2*>(st) = make_double2(cpv[0].x, cpv[1].x);
+        *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
+      }
     }
     par ^= 1;
+    cnt++;
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 2);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 1);
-    if (slot_next >= 0) extract_cols(slot_next, pp ^ 1, Ib, Jb, vb);   // reads the swept registers
-    // NOTE: a fix_depth edit touches P(rho,rho) only, never the zeta columns just extracted
-    pp ^= 1;
-    smp ^= 1;
+    __syncthreads();  // B1 (the only barrier of an update): sweeps finished; next gain rows, verdict and NaN word complete
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 3);
-    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
-    __syncthreads();  // B1
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 3);
     it_++;
     m = mnext;
@@ -815,7 +829,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 }
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
-__device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane,
+__device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane, int nww,
                                             const double* __restrict__ u_all, int* __restrict__ result_all) {
   const int N = S.N, n = S.n, len = S.len, M = S.M;
   const DevParams& prm = *a.dp;
@@ -837,8 +851,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
     RES_STAMP(S, lane == 0, 2);
     // (same wave: the LDS accesses of lane 0 above are complete before the feature lanes read ctx)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
+    wave_lds_sync();
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, S.featA, S.phiff);
     RES_STAMP(S, lane == 0, 4);
   }
@@ -898,7 +911,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // form  S = Hb P_zz Hb^T + R,  S^-1  and the gate verdict right after its prediction -- at the END of an iteration.
   // The next iteration then starts directly with the gain rows: no separate innovation phase, two barriers per update.
   int smp = 0;   // which measurement mailbox holds the CURRENT measurement {Hb, res, S^-1, verdict}
-  int pp = 0;    // which Praw buffer holds the current measurement's columns
   int m = res_next_valid(S, 0);
   RES_STAMP(S, lane == 0, 9);
   __syncthreads();  // Bp : the workers published Pd (diagonal zeta blocks) and the first measurement's columns
@@ -935,50 +947,92 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   double f1[3], f2[3], fz[3];
   bearing_frame_fast(qn, f1, f2, fz);
   const double sgn = isatt ? -1.0 : 1.0;   // q (x) e instead of e (x) q flips the cross term only
+  // Gain rows of the measurement whose mailbox is `mb`, for ALL n rows (three per lane), from the raw columns:
+  //   W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241).
+  // Feature rows come from Praw (published by the worker waves); the 16 body rows either from Praw as well (first
+  // measurement) or from the two stashed rows of that feature, brought up to date with the rank-2 update that has been
+  // swept since (`swept`, gains still in Kt / Wt; `slot` = the feature, `sb` = stash buffer).
+  // Also leaves the NaN guard (:247; a NaN in H makes every K row NaN, so testing K covers the H test) and the gate verdict
+  // for the workers' next phase.
+  const double* stash = S.Praw + 2 * n;
+  const double lamk = (lane < 16) ? S.lam[lane] : 0.0;
+  auto gain_rows = [&](const double* mb, int nanword, int gateword, bool from_stash, int sb, bool swept, int slot,
+                       const double* Kc, double* Kd) {   // Kc: gains of the update just swept, Kd: destination buffer
+    const double* Wc = Kc + 2 * n;
+    double* Wd = Kd + 2 * n;
+    const double2 hA = *reinterpret_cast<const double2*>(mb + 0), hB = *reinterpret_cast<const double2*>(mb + 2);
+    const double2 sA = *reinterpret_cast<const double2*>(mb + 6), sB = *reinterpret_cast<const double2*>(mb + 8);
+    const double gfl = mb[10];
+    double2 pr[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) pr[u] = *reinterpret_cast<const double2*>(S.Praw + 2 * min(lane + 64 * u, n - 1));
+    if (from_stash) {
+      const int k = min(lane, 15);
+      const double2 st = *reinterpret_cast<const double2*>(stash + 32 * sb + 2 * k);   // (P[j0][k], P[j0+1][k]) before ...
+      // ... the update with gains K, W -- the same expression, operand for operand, as the workers' body-column sweep
+      const double2 ka = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot));
+      const double2 kb2 = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot + 1));
+      const double2 wk = *reinterpret_cast<const double2*>(Wc + 2 * k);
+      double r0 = st.x, r1 = st.y;
+      if (swept) {
+        const double La = partial ? (lamk + lz0 - lz0 * lamk) : 1.0, Lb = partial ? (lamk + lz1 - lz1 * lamk) : 1.0;
+        r0 = fma(-La, fma(ka.y, wk.y, ka.x * wk.x), r0);
+        r1 = fma(-Lb, fma(kb2.y, wk.y, kb2.x * wk.x), r1);
+      }
+      if (lane < 16) pr[0] = make_double2(r0, r1);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int row = lane + 64 * u;
+      const double w0 = pr[u].x * hA.x + pr[u].y * hA.y, w1 = pr[u].x * hB.x + pr[u].y * hB.y;
+      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
+      if (row < n) {
+        *reinterpret_cast<double2*>(Wd + 2 * row) = make_double2(w0, w1);
+        *reinterpret_cast<double2*>(Kd + 2 * row) = make_double2(k0, k1);
+        if (k0 != k0 || k1 != k1) bad = 1;
+      }
+    }
+    bad = __any(bad);
+    if (lane == 0) { sm[nanword] = bad ? 1.0 : 0.0; sm[gateword] = gfl; }
+  };
   if (m < M && lane == S.mslot[m]) predict(f1, f2, fz, m, 0);
+  wave_lds_sync();   // the mailbox was written by ONE lane
+  if (m < M) gain_rows(sm, 44, 50, false, 0, false, 0, S.Kt, S.Kt);   // (the first raw columns were published before Bp)
   int2 sq = S.mseq[min(m, MCAP - 1)];
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
-  int it_ = 0;
+  int it_ = 0, cnt = 0;
+  lds_vint_t* rawcnt = (lds_vint_t*)(sm + 49);   // worker waves that have published the next raw columns (explicit LDS
+                                                 // pointer: a volatile access through the generic one becomes a FLAT load)
 
   while (m < M) {
     const int mnext = sq.x, slot_next = sq.y;
-    const double* Pr = S.Praw + pp * 2 * n;
     const double* mbx = sm + 16 * smp;
-    const double2 hA = *reinterpret_cast<const double2*>(mbx + 0), hB = *reinterpret_cast<const double2*>(mbx + 2),
-                  rr = *reinterpret_cast<const double2*>(mbx + 4), sA = *reinterpret_cast<const double2*>(mbx + 6),
-                  sB = *reinterpret_cast<const double2*>(mbx + 8);
+    const double2 rr = *reinterpret_cast<const double2*>(mbx + 4);
     const double gflag = mbx[10];
-    const double2 p0 = *reinterpret_cast<const double2*>(Pr + 2 * rid0), p1 = *reinterpret_cast<const double2*>(Pr + 2 * rid1),
-                  p2 = *reinterpret_cast<const double2*>(Pr + 2 * rid2);
+    // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
+    const double* kP = (cnt & 1) ? S.X : S.Kt;   // (double-buffered, see the worker side)
+    const double* wP = kP + 2 * n;
+    const double2 kA = *reinterpret_cast<const double2*>(kP + 2 * rid0), wA = *reinterpret_cast<const double2*>(wP + 2 * rid0),
+                  kB = *reinterpret_cast<const double2*>(kP + 2 * rid1), wB = *reinterpret_cast<const double2*>(wP + 2 * rid1),
+                  kC = *reinterpret_cast<const double2*>(kP + 2 * rid2);
+    const double nanw = sm[44 + cnt % 3];
     sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
     const bool gated = gflag != 0.0;
-    const double h00 = hA.x, h01 = hA.y, h10 = hB.x, h11 = hB.y, r0 = rr.x, r1 = rr.y;
-    const double Si[4] = {sA.x, sA.y, sB.x, sB.y};
+    const bool bad = nanw != 0.0;        // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows
+    const double r0 = rr.x, r1 = rr.y;
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
-    // ---- this lane's gain rows (registers only) and correction lambda o (K r)   (vi_ekf_meas.cpp:241-255): they need only
-    //      the raw columns and this wave's own mailbox, so they run while the worker waves form Kt / Wt
-    double dv0, dv1, dv2;
-    double kw[8];   // rows 0,1 of this lane: (w0,w1,k0,k1) each -- for the lane's own P_zz update
-    int bad = 0;
-    {
-      auto rowk = [&](const double2& pr, double l, double* keep) {
-        const double w0 = pr.x * h00 + pr.y * h01, w1 = pr.x * h10 + pr.y * h11;
-        const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
-        if (k0 != k0 || k1 != k1) bad = 1;
-        if (keep) { keep[0] = w0; keep[1] = w1; keep[2] = k0; keep[3] = k1; }
-        return (l * k0) * r0 + (l * k1) * r1;
-      };
-      dv0 = rowk(p0, lam0, kw); dv1 = rowk(p1, lam1, kw + 4); dv2 = rowk(p2, lam2, nullptr);
-      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
-      bad = __any(bad);   // the 64 lanes together cover every row of K
-    }
+    // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
+    const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
+    const double dv1 = (lam1 * kB.x) * r0 + (lam1 * kB.y) * r1;
+    const double dv2 = (lam2 * kC.x) * r0 + (lam2 * kC.y) * r1;
+    const double kw[8] = {wA.x, wA.y, kA.x, kA.y, wB.x, wB.y, kB.x, kB.y};   // (w0,w1,k0,k1) of rows 0,1
     // rotation vector of the correction: bearing  T_zeta [d0 d1],  attitude  [d0 d1 d2]
     double v[3];
     v[0] = isatt ? dv0 : (f1[0] * dv0 + f2[0] * dv1);
     v[1] = isatt ? dv1 : (f1[1] * dv0 + f2[1] * dv1);
     v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
-    __syncthreads();  // B2 : (the workers wrote the gain rows Kt / Wt; this wave only passes through)
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
     const bool corr = !gated && !bad && !(S.dbg & 2);
@@ -1003,7 +1057,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
-    if (lane == 0) { sm[40 + par] = 0.0; sm[44 + (smp ^ 1)] = 0.0; }
+    if (lane == 0) sm[40 + par] = 0.0;
     if (!gated && isfeat && lane < len) {   // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238)
       double rho = lin;
       if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
@@ -1022,11 +1076,20 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     }
     if (lane == slot_next) predict(f1, f2, fz, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
+    if (slot_next >= 0) {
+      // The worker waves publish the next raw feature rows right after their block sweeps, long before this point; the count
+      // is polled (never a barrier): the workers wait for this wave only at the barrier below, so the wait cannot deadlock.
+      int spins = 0;
+      while (*rawcnt < nww * (cnt + 1) && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); spins++; }
+      wave_lds_sync();   // the mailbox was written by ONE lane; the raw columns by other waves (count above)
+      gain_rows(sm + 16 * (smp ^ 1), 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), true, (cnt + 1) & 1, !gated && !bad && !(S.dbg & 1),
+                slot_next, kP, (cnt & 1) ? S.Kt : S.X);
+    }
     par ^= 1;
     smp ^= 1;
-    pp ^= 1;
+    cnt++;
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 2);
-    __syncthreads();  // B1
+    __syncthreads();  // B1 (the only barrier of an update)
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 3);
     it_++;
     m = mnext;
@@ -1073,7 +1136,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
-    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; }
+    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
       const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];
@@ -1113,7 +1176,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   if ((int)blockIdx.x >= a.B) return;
   ResShared S;
   res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
-  if (tid >= TW) res_service(a, S, tid - TW, u_all, result_all);
+  if (tid >= TW) res_service(a, S, tid - TW, NW, u_all, result_all);
   else res_worker<RB, TW>(a, S, TR, TD, tid);
 }
 
