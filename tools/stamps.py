@@ -29,17 +29,18 @@ print("service: B0 wait", d(0, 1), " body phase", d(1, 2), " B1p wait", d(2, 3),
       " body step+fix", d(5, 6), " B3p wait", d(6, 7), " B4p wait (GEMM)", d(7, 8), " first h_feat", d(8, 9), " B1 wait", d(9, 10))
 print("worker : load->B0", d(63, 64), " B0 wait", d(64, 65), " to B3p", d(65, 66), " B3p wait", d(66, 67), " local3x3", d(67, 68),
       " GEMM", d(68, 69), " strips", d(69, 70), " B4p+extract->B1", d(70, 71))
+# one barrier per update (B1).  service: 16+4it+{0: phase inputs loaded, 1: rotation vector ready, 2: gain rows of the next
+# measurement written (before B1), 3: after B1}; 128+4it+{0,1}: around the manifold correction.  worker (thread 0):
+# 80+4it+{1: phase top, 2: before B1, 3: after B1}; 160+4it+{0: blocks swept, 1: raw columns published + counted in}.
 for it in range(8):
-    s0 = 16 + 4 * it; w0 = 80 + 4 * it
-    print("update %d  service: gain %5d | B2 wait %5d | correct+h %5d | B1 wait %5d     worker: B2 wait %5d | sweep %5d | extract %5d | B1 wait(next) " % (
-        it, d(s0 - 1 if it else 10, s0), d(s0, s0 + 1), d(s0 + 1, s0 + 2), d(s0 + 2, s0 + 3), d(w0, w0 + 1), d(w0 + 1, w0 + 2), d(w0 + 2, w0 + 3)))
-for it in range(4):
-    s0 = 16 + 4 * it; q0 = 128 + 4 * it
-    print("update %d service detail: rows+dv %5d | boxplus %5d | fix+h_feat %5d" % (it, d(s0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, s0 + 2)))
-for it in range(4):
-    w0 = 80 + 4 * it; q0 = 160 + 4 * it
-    print("update %d worker detail: blocks %5d | body cols %5d | body block %5d" % (it, d(w0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, w0 + 2)))
+    s0 = 16 + 4 * it; w0 = 80 + 4 * it; q0 = 160 + 4 * it; b0 = 128 + 4 * it
+    print("update %d  service: inputs %5d | correction %5d | fix+predict+poll+gain rows %5d | B1 wait %5d      worker0: blocks %5d | "
+          "publish+count %5d | body columns %5d | B1 wait %5d" % (
+              it, d(s0 - 1 if it else 10, s0), d(s0, b0 + 1), d(b0 + 1, s0 + 2), d(s0 + 2, s0 + 3),
+              d(w0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, w0 + 2), d(w0 + 2, w0 + 3)))
+it = 3
 for w in range(7):
-    q0 = 192 + 4 * w
-    print("update 3 worker wave %d: sweep %5d | extract %5d | B1 wait %5d   (B2-pass skew vs wave 0: %d)" % (w, d(q0, q0 + 1), d(q0 + 1, q0 + 2), d(q0 + 2, q0 + 3), d(192, q0)))
-print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(63, 73))
+    q = 192 + 4 * w
+    print("update 3 worker wave %d: phase top -> before B1 %5d | B1 wait %5d   (top skew vs wave 0: %d)" % (
+        w, d(q, q + 1), d(q + 1, q + 3), int(t[q] - t[192])))
+print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(62, 73))

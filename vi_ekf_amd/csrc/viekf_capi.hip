@@ -142,6 +142,7 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 struct ResInst { int RB, NW, nmin, nmax; };
 const ResInst kResInst[] = {
     {3, 7, 1, 50},
+    {4, 6, 1, 50},   // 4 blocks per thread on 6 worker waves (the service wave alone on its SIMD): measured 4 % slower
 };
 
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
@@ -149,14 +150,17 @@ typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const dou
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
     case 0: return k_step_resident<3, 7>;
+    case 1: return k_step_resident<4, 6>;
   }
   return nullptr;
 }
 
 int setup_resident(viekf_batch* b) {
   b->res_inst = -1;
+  const char* force = getenv("VIEKF_RES_INST");   // (experiments: pick an instance by index)
   for (int i = 0; i < (int)(sizeof(kResInst) / sizeof(kResInst[0])); i++) {
     const ResInst& r = kResInst[i];
+    if (force && atoi(force) != i) continue;
     if (b->N < r.nmin || b->N > r.nmax) continue;
     const int TR = (b->N + r.RB - 1) / r.RB, TC = b->N / 2 + 1;   // TC holds TD, the number of wrapped diagonals
     if (TR * TC > r.NW * 64) continue;

@@ -654,26 +654,24 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia]) = make_double2(pb[ia][0], pb[ia][1]);
       *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia] + 2) = make_double2(pb[ia][3], pb[ia][4]);
     }
-  // body-column item of this thread (constant): feature ig, body columns ij, ij+1
-  const bool ihas = tid < 8 * N;
-  const int ig = min(tid >> 3, N - 1), ij = (tid & 7) * 2;
   double* stash = S.Praw + 2 * n;   // [2][16][2]: rows j0, j0+1 x body columns of a LATER measurement's feature (see below)
   int2 sq = S.mseq[min(m, MCAP - 1)];
   if (m < S.M) {
     apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
     const int s0 = S.mslot[m];
     extract_cols(s0);
-    if (ihas && ig == s0) {   // body rows of the first measurement's columns (P[k][j0+c] = P[j0+c][k])
-      const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * s0) * 16 + ij);
-      const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * s0 + 1) * 16 + ij);
-      *reinterpret_cast<double2*>(S.Praw + 2 * ij) = make_double2(q0.x, q1.x);
-      *reinterpret_cast<double2*>(S.Praw + 2 * ij + 2) = make_double2(q0.y, q1.y);
-    }
-    if (ihas && ig == sq.y) {   // ... and the same rows of the SECOND measurement's feature, for the service wave (phase 0)
-      const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * ig) * 16 + ij);
-      const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * ig + 1) * 16 + ij);
-      *reinterpret_cast<double2*>(stash + 32 + 2 * ij) = make_double2(q0.x, q1.x);
-      *reinterpret_cast<double2*>(stash + 32 + 2 * ij + 2) = make_double2(q0.y, q1.y);
+    // body rows of the first measurement's columns (P[k][j0+c] = P[j0+c][k]) and, for the service wave's phase 0, the same
+    // rows of the SECOND measurement's feature: 8 threads each, two body columns per thread
+    const int e = opaque(tid);
+    if (e < 16) {
+      const int sf = (e < 8) ? s0 : sq.y, ijj = (e & 7) * 2;
+      if (sf >= 0) {
+        const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * sf) * 16 + ijj);
+        const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * sf + 1) * 16 + ijj);
+        double* d = (e < 8) ? (S.Praw + 2 * ijj) : (stash + 32 + 2 * ijj);
+        *reinterpret_cast<double2*>(d) = make_double2(q0.x, q1.x);
+        *reinterpret_cast<double2*>(d + 2) = make_double2(q0.y, q1.y);
+      }
     }
   }
   RES_STAMP(S, tid == 0, 71);
@@ -734,10 +732,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- (3) body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
-    //      8 N items spread over all worker waves; the row lambdas are the lambda_feat constants, no per-row loads.
-    {
-      const bool hasc = ihas;
-      const int g = ig, j2 = ij;
+    //      8 N items over the worker threads; the row lambdas are the lambda_feat constants, no per-row loads.
+#pragma unroll 1
+    for (int item = it; item < 8 * N; item += TW) {
+      const int g = item >> 3, j2 = (item & 7) * 2;
       double2 cpv[3];
 #pragma unroll
       for (int q = 0; q < 3; q++) cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
@@ -748,35 +746,36 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         double2 cki[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) cki[q] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * g + q));
-        // body block: 2 adjacent elements per thread, on the top 128 threads
-        const int ib = it - (TW - 128);
-        const int br = max(ib, 0) >> 3, bc2 = (max(ib, 0) & 7) * 2;
-        const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
-        const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
-        const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
-        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
-        const double blr = S.lam[br];
-        double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           const double L0 = partial ? (clk.x + lfe[q] - lfe[q] * clk.x) : 1.0;
           const double L1 = partial ? (clk.y + lfe[q] - lfe[q] * clk.y) : 1.0;
           cpv[q].x = fma(-L0, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
           cpv[q].y = fma(-L1, fma(cki[q].y, cw1.y, cki[q].x * cw1.x), cpv[q].y);
-          if (hasc) *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
-        }
-        if (ib >= 0) {
-          const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
-          bpv.x = fma(-L0, fma(bkr.y, bw0.y, bkr.x * bw0.x), bpv.x);
-          bpv.y = fma(-L1, fma(bkr.y, bw1.y, bkr.x * bw1.x), bpv.y);
-          *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
+          *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
         }
       }
       // rows j0, j0+1 of the feature measured two phases from now, as they stand after this phase's sweep
-      if (hasc && g == sq.y) {
+      if (g == sq.y) {
         double* st = stash + 32 * (cnt & 1) + 2 * j2;
         *reinterpret_cast<double2*>(st) = make_double2(cpv[0].x, cpv[1].x);
         *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
+      }
+    }
+    if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads
+      const int ib = it - (TW - 128);
+      if (ib >= 0) {
+        const int br = ib >> 3, bc2 = (ib & 7) * 2;
+        const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
+        const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
+        const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
+        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
+        const double blr = S.lam[br];
+        double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
+        const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
+        bpv.x = fma(-L0, fma(bkr.y, bw0.y, bkr.x * bw0.x), bpv.x);
+        bpv.y = fma(-L1, fma(bkr.y, bw1.y, bkr.x * bw1.x), bpv.y);
+        *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
       }
     }
     par ^= 1;
@@ -1176,8 +1175,13 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   if ((int)blockIdx.x >= a.B) return;
   ResShared S;
   res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
-  if (tid >= TW) res_service(a, S, tid - TW, NW, u_all, result_all);
-  else res_worker<RB, TW>(a, S, TR, TD, tid);
+  // The service wave's chain is the floor of an update, so it should not share its SIMD's issue slots with a worker wave.  A
+  // workgroup's waves go to the four SIMDs round-robin: with 7 waves (NW = 6) the 4th one is alone on its SIMD -- that is
+  // the service wave.  With 8 waves (NW = 7) every SIMD holds two and the last wave serves.
+  constexpr int SVC = (NW == 6) ? 3 : NW;
+  const int wave = tid >> 6;
+  if (wave == SVC) res_service(a, S, tid & 63, NW, u_all, result_all);
+  else res_worker<RB, TW>(a, S, TR, TD, tid - (wave > SVC ? 64 : 0));
 }
 
 }  // namespace viekf
