@@ -147,6 +147,13 @@ int viekf_batch_update_feat(viekf_batch *b, const double *z, const int32_t *slot
  * (:119-139) is host bookkeeping and stays with the caller. */
 int viekf_batch_keep_features(viekf_batch *b, const uint8_t *keep, int32_t *new_len, viekf_mem where);
 
+/* Keyframe reset (VIEKF::keyframe_reset, src/vi_ekf/vi_ekf_kfr.cpp:56-157): position <- 0, yaw <- 0, P <- N P N^T.
+ * mask [batch] (NULL = every filter): which filters reset (the overlap test of keep_only_features, vi_ekf_feat.cpp:99-104,
+ * is the caller's).  edge [batch][17] (may be NULL): the relative pose that the reference folds into its global node frame,
+ * {t(3), q_yaw(4; w,x,y,z), cov_pos(9, column-major 3x3), cov_yaw}; the composition itself (:147-149) uses the Xformd algebra
+ * of the reference's `geometry` dependency and stays on the caller's side. */
+int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge, viekf_mem where);
+
 /* Bounded device-side history for delayed measurements (the reference rewinds its 250-deep ring of (x,P,t),
  * include/vi_ekf.h:50,156-160, src/vi_ekf/vi_ekf_meas.cpp:45-63).  viekf_batch_history_resize allocates `depth`
  * snapshot slots of the whole batch (depth * batch * (8 n ld + 8 nx) bytes: choose it, the reference's 250 would be

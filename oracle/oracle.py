@@ -85,6 +85,7 @@ def lib():
         L.vo_update.argtypes = [_fp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int]
         L.vo_update.restype = C.c_int
         L.vo_keyframe_reset.argtypes = [_fp]
+        L.vo_keyframe_reset_edge.argtypes = [_fp, _dp]
         for nm in ("vo_nans_in_the_house", "vo_blowing_up", "vo_negative_depth"):
             getattr(L, nm).argtypes = [_fp]
             getattr(L, nm).restype = C.c_int
@@ -271,6 +272,12 @@ class OracleFilter:
                                      int(active), int(id)))
 
     def keyframe_reset(self): self._L.vo_keyframe_reset(self._p)
+
+    def keyframe_reset_edge(self):
+        """keyframe reset that also returns the edge {t(3), q_yaw(4), cov_pos(9, column-major), cov_yaw}"""
+        e = np.zeros(17)
+        self._L.vo_keyframe_reset_edge(self._p, _d(e))
+        return e
     def nans_in_the_house(self): return bool(self._L.vo_nans_in_the_house(self._p))
     def blowing_up(self): return bool(self._L.vo_blowing_up(self._p))
     def negative_depth(self): return bool(self._L.vo_negative_depth(self._p))

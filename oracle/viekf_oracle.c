@@ -827,12 +827,22 @@ int vo_update(vo_filter *f, int type, const double *z, int zdim, const double *R
 
 /* ------------------------------------------------------------------ keyframe reset (vi_ekf_kfr.cpp:56-157, "Dan's way") */
 
-void vo_keyframe_reset(vo_filter *f) {
+/* edge (optional, 17 doubles): what the reference keeps of the relative pose before it is reset (:58-62,125-126) --
+ * t(3) = position, q(4) = from_euler(0,0,yaw), cov_pos(9) = P[pos,pos] column-major, cov_yaw = P(xATT+2, xATT+2).  The
+ * composition into the global node pose / covariance (:147-149) uses Xformd of the absent `geometry` library and is left
+ * to the caller. */
+void vo_keyframe_reset_edge(vo_filter *f, double *edge) {
   const int n = f->n;
-  for (int i = 0; i < 3; i++) f->x[VO_xPOS + i] = 0.0;         /* :65 */
   double *q = f->x + VO_xATT;
   double yaw = q_yaw(q), roll = q_roll(q), pitch = q_pitch(q); /* :120-122 */
-  (void)yaw;
+  if (edge) {
+    for (int i = 0; i < 3; i++) edge[i] = f->x[VO_xPOS + i];   /* :61 */
+    q_from_euler(0.0, 0.0, yaw, edge + 3);                     /* :125 */
+    for (int j = 0; j < 3; j++)
+      for (int i = 0; i < 3; i++) edge[7 + i + 3 * j] = AT(f->P, n, VO_dxPOS + i, VO_dxPOS + j);   /* :62 */
+    edge[16] = AT(f->P, n, VO_dxATT + 2, VO_dxATT + 2);        /* :126 */
+  }
+  for (int i = 0; i < 3; i++) f->x[VO_xPOS + i] = 0.0;         /* :65 */
   double qn[4];
   q_from_euler(roll, pitch, 0.0, qn);                          /* :129 */
   memcpy(q, qn, sizeof qn);
@@ -849,6 +859,8 @@ void vo_keyframe_reset(vo_filter *f) {
   mmT(n, n, n, AP, n, A, n, APAT, n);
   memcpy(f->P, APAT, sizeof(double) * (size_t)n * n);
 }
+
+void vo_keyframe_reset(vo_filter *f) { vo_keyframe_reset_edge(f, 0); }
 
 /* ------------------------------------------------------------------ error predicates (vi_ekf_error.cpp:6-38) */
 

@@ -100,6 +100,7 @@ void vo_h(const vo_filter *f, int type, const double *x, double *h /*4*/, double
 int  vo_update(vo_filter *f, int type, const double *z, int zdim, const double *R, int rdim, int active, int id);
 /* vi_ekf_kfr.cpp:56-157 (Dan's way); N (n x n) receives A_ */
 void vo_keyframe_reset(vo_filter *f);
+void vo_keyframe_reset_edge(vo_filter *f, double *edge /* 17 or NULL */);
 /* vi_ekf_error.cpp:6-38 */
 int vo_nans_in_the_house(const vo_filter *f);
 int vo_blowing_up(const vo_filter *f);

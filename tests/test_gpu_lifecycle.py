@@ -71,3 +71,39 @@ def test_snapshot_restore_replays_identically():
     assert np.array_equal(g.get_state(), x3) and np.array_equal(g.get_covariance(), P3)
     with pytest.raises(v.ViekfError):
         g.snapshot(2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [5, 50])
+def test_keyframe_reset_matches_oracle(N):
+    """device keyframe reset (state, N P N^T, edge) vs the oracle's restatement of vi_ekf_kfr.cpp:56-157"""
+    import vi_ekf_amd as v
+    from vi_ekf_amd import scene
+    from oracle import oracle as orc
+    from tests.test_gpu_parity import assert_close
+    B = 3
+    sc = scene.make_scene(B, N, 3, seed=11)
+    prm = {k: sc["params"][k] for k in sc["params"] if k not in ("name", "keyframe_overlap_threshold")}
+    g = v.BatchVIEKF(B, N, sc["params"])
+    fs = [orc.OracleFilter(N).init(**prm) for _ in range(B)]
+    for i in range(N):
+        g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        for b in range(B):
+            fs[b].init_feature(sc["pix"][b, i], i, float("nan"))
+    R = np.asarray(sc["R"]).reshape(2, 2)
+    for s in range(3):   # a few steps so that attitude, position and P are generic
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+        for b in range(B):
+            fs[b].propagate(sc["u"][s][b], float(sc["dt"][b]))
+            for k in range(N):
+                fs[b].update(orc.FEAT, sc["z"][s][b, k], R, True, int(sc["slot"][b, k]))
+    mask = np.array([1, 0, 1], dtype=np.uint8)
+    edge = g.keyframe_reset(mask)
+    ref_edge = np.zeros((B, 17))
+    for b in range(B):
+        if mask[b]:
+            ref_edge[b] = fs[b].keyframe_reset_edge()
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x after keyframe reset")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after keyframe reset")
+    assert_close(edge, ref_edge, "edge")
+    assert np.all(g.get_state()[mask == 1, 0:3] == 0.0)

@@ -217,6 +217,18 @@ class BatchVIEKF:
         self._keep = []
         return nl
 
+    def keyframe_reset(self, mask=None):
+        """keyframe reset of the filters with mask[b] != 0 (None = all), reference vi_ekf_kfr.cpp:56-157.
+        Returns the edges [B][17] = {t(3), q_yaw(4), cov_pos(9, column-major), cov_yaw} (zeros outside the mask)."""
+        self._keep = []
+        pm = None
+        if mask is not None:
+            pm, _ = self._arg(mask, np.uint8, (self.B,), None)
+        edge = np.zeros((self.B, 17), dtype=np.float64)
+        capi.check(capi.lib().viekf_batch_keyframe_reset(self._h, pm, C.c_void_p(edge.ctypes.data), capi.HOST))
+        self._keep = []
+        return edge
+
     def history_resize(self, depth):
         capi.check(capi.lib().viekf_batch_history_resize(self._h, int(depth)))
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "viekf_batch_sync", "viekf_batch_set_kernel", "viekf_batch_get_state", "viekf_batch_set_state",
     "viekf_batch_get_status", "viekf_batch_propagate", "viekf_batch_init_feature", "viekf_batch_update_feat",
     "viekf_batch_step", "viekf_batch_update", "viekf_batch_keep_features", "viekf_batch_history_resize",
-    "viekf_batch_snapshot", "viekf_batch_restore",
+    "viekf_batch_snapshot", "viekf_batch_restore", "viekf_batch_keyframe_reset",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
         L.viekf_batch_update_feat.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int]
         L.viekf_batch_update.argtypes = [_vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_keep_features.argtypes = [_vp, _vp, _vp, C.c_int]
+        L.viekf_batch_keyframe_reset.argtypes = [_vp, _vp, _vp, C.c_int]
         L.viekf_batch_history_resize.argtypes = [_vp, C.c_int32]
         L.viekf_batch_snapshot.argtypes = [_vp, C.c_int32]
         L.viekf_batch_restore.argtypes = [_vp, C.c_int32]

@@ -590,6 +590,28 @@ int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_
   return VIEKF_OK;
 }
 
+int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  const uint8_t* d_mask = nullptr;
+  double* d_edge = nullptr;
+  const size_t eb = sizeof(double) * 17 * (size_t)b->B;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size((size_t)b->B) + stage_size(eb))) return rc;
+  if (mask)
+    if (int rc = in_ptr(b, mask, (size_t)b->B, where, &d_mask)) return rc;
+  if (edge) d_edge = where == VIEKF_DEVICE ? edge : static_cast<double*>(stage_take(b, eb));
+  if (edge && where == VIEKF_HOST) HIP_TRY(hipMemsetAsync(d_edge, 0, eb, b->stream));   // filters outside the mask report zeros
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_keyframe_reset<kThreads>, dim3(b->B), dim3(kThreads), 0, b->stream, a, d_mask, d_edge);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (edge) HIP_TRY(hipMemcpyAsync(edge, d_edge, eb, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
 int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
   if (int rc = check_batch(b)) return rc;
   if (depth < 0 || depth > 4096) return fail(VIEKF_ERR_INVALID, "0 <= depth <= 4096");

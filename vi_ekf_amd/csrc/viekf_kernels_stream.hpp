@@ -737,6 +737,63 @@ __global__ __launch_bounds__(T) void k_keep_features(StreamArgs a, const unsigne
   if (tid == 0) { a.len[b] = k; if (new_len) new_len[b] = k; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// keyframe reset ("Dan's way", vi_ekf_kfr.cpp:56-157): position <- 0, yaw <- 0, P <- N P N^T where N differs from I only
+// in the position block (0) and the attitude block (RMEKF Eq. 81).  One workgroup per filter, in place: first the row
+// operation N P (every thread owns columns), then the column operation (every thread owns rows).  edge [B][17] (optional):
+// {t(3), q_yaw(4), cov_pos(9, column-major), cov_yaw} of the relative pose before the reset, for the caller's global-pose
+// bookkeeping (:58-62,125-126,147-149 -- the Xformd algebra of the reference's `geometry` dependency stays with the caller).
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_keyframe_reset(StreamArgs a, const unsigned char* __restrict__ mask,
+                                                      double* __restrict__ edge_all) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  if (mask && !mask[b]) return;
+  const int n = a.n, ld = a.ld;
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const double* q = xg + xATT;
+  const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  const double yaw = atan2(2.0 * (qw * qz + qx * qy), 1.0 - 2.0 * (qy * qy + qz * qz));     // src/quat.cpp:221-224
+  const double roll = atan2(2.0 * (qw * qx + qy * qz), 1.0 - 2.0 * (qx * qx + qy * qy));    // :211-214
+  const double pitch = asin(2.0 * (qw * qy - qz * qx));                                     // :216-219
+  const double cp = cos(roll), sp = sin(roll), tt = tan(pitch);                             // vi_ekf_kfr.cpp:134-136
+  const double Na[9] = {1.0, sp * tt, cp * tt, 0.0, cp * cp, -cp * sp, 0.0, -cp * sp, sp * sp};   // row-major (:139-142)
+  if (edge_all && tid == 0) {
+    double* e = edge_all + (long)b * 17;
+    for (int i = 0; i < 3; i++) e[i] = xg[xPOS + i];
+    e[3] = cos(yaw / 2.0); e[4] = 0.0; e[5] = 0.0; e[6] = sin(yaw / 2.0);                   // from_euler(0,0,yaw), :150-165
+    for (int j = 0; j < 3; j++)
+      for (int i = 0; i < 3; i++) e[7 + i + 3 * j] = P[(dxPOS + i) + (long)(dxPOS + j) * ld];
+    e[16] = P[(dxATT + 2) + (long)(dxATT + 2) * ld];
+  }
+  __syncthreads();   // (the edge reads P and x before they change)
+  // rows: T = N P
+  for (int j = tid; j < n; j += T) {
+    double* c = P + (long)j * ld;
+    const double a0 = c[dxATT], a1 = c[dxATT + 1], a2 = c[dxATT + 2];
+    c[dxATT] = Na[0] * a0 + Na[1] * a1 + Na[2] * a2;
+    c[dxATT + 1] = Na[3] * a0 + Na[4] * a1 + Na[5] * a2;
+    c[dxATT + 2] = Na[6] * a0 + Na[7] * a1 + Na[8] * a2;
+    c[dxPOS] = 0.0; c[dxPOS + 1] = 0.0; c[dxPOS + 2] = 0.0;
+  }
+  __syncthreads();
+  // columns: P = T N^T
+  for (int i = tid; i < n; i += T) {
+    const double a0 = P[i + (long)dxATT * ld], a1 = P[i + (long)(dxATT + 1) * ld], a2 = P[i + (long)(dxATT + 2) * ld];
+    P[i + (long)dxATT * ld] = a0 * Na[0] + a1 * Na[1] + a2 * Na[2];
+    P[i + (long)(dxATT + 1) * ld] = a0 * Na[3] + a1 * Na[4] + a2 * Na[5];
+    P[i + (long)(dxATT + 2) * ld] = a0 * Na[6] + a1 * Na[7] + a2 * Na[8];
+    P[i + (long)dxPOS * ld] = 0.0; P[i + (long)(dxPOS + 1) * ld] = 0.0; P[i + (long)(dxPOS + 2) * ld] = 0.0;
+  }
+  if (tid == 0) {
+    const double cr = cos(roll / 2.0), ct = cos(pitch / 2.0), sr = sin(roll / 2.0), st = sin(pitch / 2.0);
+    xg[xPOS] = 0.0; xg[xPOS + 1] = 0.0; xg[xPOS + 2] = 0.0;                                  // :65
+    xg[xATT] = cr * ct; xg[xATT + 1] = sr * ct; xg[xATT + 2] = cr * st; xg[xATT + 3] = -sr * st;   // from_euler(roll,pitch,0)
+  }
+}
+
 // fill every filter with the initial state (vi_ekf.cpp:70-81 / :134-144)
 __global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, const double* __restrict__ Pdiag /*n*/) {
   const int b = blockIdx.x;
