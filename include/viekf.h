@@ -111,6 +111,7 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params *
 int viekf_batch_destroy(viekf_batch *b);
 int viekf_batch_reset(viekf_batch *b);    /* back to the state viekf_batch_create left */
 int viekf_batch_dims(const viekf_batch *b, int32_t *batch, int32_t *num_features, int32_t *nx, int32_t *n);
+int viekf_batch_get_params(const viekf_batch *b, viekf_params *out);   /* the parameter set the batch was created with */
 /* run all later calls of this batch on a caller-owned hipStream_t (e.g. torch's current stream);
  * NULL = HIP's default (null) stream.  A new batch starts on a private non-blocking stream. */
 int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
@@ -166,14 +167,47 @@ int viekf_batch_restore(viekf_batch *b, int32_t slot);
  * h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, src/vi_ekf/vi_ekf_meas.cpp:196-386.
  * type: viekf_meas_type.  z [batch][zdim] (ATT/QZETA: quaternion, zdim 4).  R: rdim x rdim column-major,
  * r_mode 0 = shared, 1 = R[batch][rdim*rdim].  slot [batch]: local feature index for QZETA/FEAT/DEPTH/INV_DEPTH
- * (NULL otherwise).  active [batch] (NULL = all active): an inactive measurement only runs fix_depth, as in the
- * reference (:230).  result [batch]: viekf_meas_result. */
+ * (NULL otherwise).  active [batch] (NULL = all active): 0 = an inactive measurement, which only runs fix_depth as in the
+ * reference (:230); 2 = the filter takes no part in this call (result VIEKF_MEAS_SKIPPED).  result [batch]: viekf_meas_result. */
 int viekf_batch_update(viekf_batch *b, int32_t type, const double *z, int32_t zdim, const double *R, int32_t rdim,
                        int32_t r_mode, const int32_t *slot, const uint8_t *active, int32_t *result, viekf_mem where);
 
 /* one hot-path step = propagate + M feature updates, fused where the kernel family allows */
 int viekf_batch_step(viekf_batch *b, const double *u, const double *dt, const double *z, const int32_t *slot,
                      int32_t M, const double *R, int32_t r_mode, int32_t *result, viekf_mem where);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Host sequencer on top of a batch whose filters share ONE clock (same IMU / measurement timestamps, different data):
+ * the queueing, rewind and replay logic of the reference class, batched.  All pointers are HOST memory.
+ *   viekf_seq_propagate            VIEKF::propagate_state(u, t, save_input = true)   src/vi_ekf/vi_ekf.cpp:262-318
+ *   viekf_seq_add_measurement      VIEKF::add_measurement                            src/vi_ekf/vi_ekf_meas.cpp:130-194
+ *   viekf_seq_handle_measurements  VIEKF::handle_measurements                        src/vi_ekf/vi_ekf_meas.cpp:6-127
+ *   viekf_seq_keep_only_features   VIEKF::keep_only_features (+ keyframe trigger)    src/vi_ekf/vi_ekf_feat.cpp:81-142
+ *   viekf_seq_tracked_features     VIEKF::tracked_features                           src/vi_ekf/vi_ekf_feat.cpp:75-78
+ * The state history (x, P, t) ring (include/vi_ekf.h:50,156-160; 250 deep there) is the batch's device snapshot ring with
+ * `state_hist` slots; a rewind restores x and P but not the feature count, like the reference's ring.  Quirks kept: the
+ * input queue stores the input already rotated by q_b_u and the replay rotates it again (vi_ekf.cpp:265-271); a feature
+ * measurement with an unknown id initialises the feature at the CURRENT state and is not queued (:140-147); features are
+ * numbered by the filter itself (vi_ekf_feat.cpp:29-30).
+ * Lockstep: the control flow (which measurement is handled, rewind target, replay) is decided once for the whole batch from
+ * the shared times.  A filter that did not queue an entry (NaN measurement, new feature) skips that update but takes part
+ * in the rewind / replay of the others -- identical to an independent reference filter whenever q_b_u is the identity or
+ * all filters queue the same entries. */
+typedef struct viekf_seq viekf_seq;
+int viekf_seq_create(viekf_batch *core, int32_t state_hist, int32_t meas_hist, viekf_seq **out);
+int viekf_seq_destroy(viekf_seq *s);
+int viekf_seq_propagate(viekf_seq *s, const double *u /* [batch][6] */, double t);
+/* z [batch][zdim]; R rdim x rdim column-major, shared; id [batch] global feature id (NULL = -1); depth [batch] (NULL = NaN);
+ * result [batch] (may be NULL): viekf_meas_result per filter */
+int viekf_seq_add_measurement(viekf_seq *s, double t, int32_t type, const double *z, int32_t zdim, const double *R,
+                              int32_t rdim, int32_t active, const int32_t *id, const double *depth, int32_t *result);
+/* gated_ids [batch][cap] / gated_count [batch] (both may be NULL): global ids of the FEAT measurements gated in this call */
+int viekf_seq_handle_measurements(viekf_seq *s, int32_t *gated_ids, int32_t cap, int32_t *gated_count);
+/* ids [batch][count] global ids to keep (pad with -1); did_reset [batch], edges [batch][17] (may be NULL): keyframe resets
+ * triggered by the overlap test and their edges (viekf_batch_keyframe_reset) */
+int viekf_seq_keep_only_features(viekf_seq *s, const int32_t *ids, int32_t count, uint8_t *did_reset, double *edges);
+int viekf_seq_tracked_features(viekf_seq *s, int32_t *ids /* [batch][num_features] */, int32_t *len /* [batch] */);
+int viekf_seq_status(viekf_seq *s, double *t_now, int32_t *ring_index, int32_t *queued, int32_t *inputs);
 
 #ifdef __cplusplus
 }

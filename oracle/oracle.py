@@ -84,6 +84,8 @@ def lib():
         L.vo_h.argtypes = [_fp, C.c_int, _dp, _dp, _dp, C.c_int]
         L.vo_update.argtypes = [_fp, C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int]
         L.vo_update.restype = C.c_int
+        L.vo_global_to_local_feature_id.argtypes = [_fp, C.c_int]
+        L.vo_global_to_local_feature_id.restype = C.c_int
         L.vo_keyframe_reset.argtypes = [_fp]
         L.vo_keyframe_reset_edge.argtypes = [_fp, _dp]
         for nm in ("vo_nans_in_the_house", "vo_blowing_up", "vo_negative_depth"):
@@ -223,6 +225,14 @@ class OracleFilter:
     @property
     def feature_ids(self):
         return [self._p.contents.feature_ids[i] for i in range(self.len_features)]
+
+    @property
+    def q_b_u(self): return np.array(self._p.contents.q_b_u)
+    @property
+    def use_keyframe_reset(self): return bool(self._p.contents.use_keyframe_reset)
+
+    def global_to_local_feature_id(self, gid):
+        return int(self._L.vo_global_to_local_feature_id(self._p, int(gid)))
 
     def set_drag_term(self, v): self._p.contents.use_drag_term = int(v)
     def set_partial_update(self, v): self._p.contents.use_partial_update = int(v)

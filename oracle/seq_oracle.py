@@ -1,0 +1,202 @@
+"""TEST INFRASTRUCTURE (parity unpinned): the host plumbing of vi_ekf::VIEKF around ONE
+oracle filter -- state ring, input deque, measurement queue with rewind / replay -- restated line by line from the
+reference:
+
+  propagate_state bookkeeping    src/vi_ekf/vi_ekf.cpp:262-318
+  add_measurement                src/vi_ekf/vi_ekf_meas.cpp:130-194
+  handle_measurements            src/vi_ekf/vi_ekf_meas.cpp:6-127
+  keep_only_features             src/vi_ekf/vi_ekf_feat.cpp:81-142
+  ring sizes                     include/vi_ekf.h:50-51
+
+Only tests/ import this.  Pure Python over oracle.OracleFilter: meant for the small functional configuration (SURVEY 8d,
+config 1).  Quirks kept: the input deque stores the ROTATED input and the replay rotates it again (vi_ekf.cpp:265-271 with
+vi_ekf_meas.cpp:78,102,111,118); a measurement newer than the newest input is left in the queue (:24-28); the rewind picks
+the newest ring slot with t <= the input before the measurement (:45-56); init_feature numbers features itself
+(vi_ekf_feat.cpp:29-30).
+"""
+import math
+from collections import deque
+
+import numpy as np
+
+from . import oracle as orc
+
+LEN_STATE_HIST = 250
+LEN_MEAS_HIST = 200
+
+
+class _Meas:
+    __slots__ = ("t", "type", "z", "R", "active", "id", "depth", "handled")
+
+
+class SeqOracle:
+    def __init__(self, filt, keyframe_overlap_threshold=0.8, state_hist=LEN_STATE_HIST, meas_hist=LEN_MEAS_HIST):
+        self.f = filt
+        self.H = int(state_hist)
+        self.MH = int(meas_hist)
+        self.xr = [None] * self.H
+        self.Pr = [None] * self.H
+        self.lr = [0] * self.H              # len_features per slot is NOT in the reference ring (x_, P_, t_ only) -- see _load
+        self.t = [math.nan] * self.H
+        self.i = 0
+        self.u = deque()                    # (t, ub) newest first
+        self.zbuf = deque()                 # newest first
+        self.start_t = math.nan
+        self.kf_thresh = float(keyframe_overlap_threshold)
+        self.keyframe_features = []
+        self.log = []                       # what would go to cerr
+        self.keyframe_edges = []
+        self._save()
+
+    # -- ring <-> live filter -------------------------------------------------------------------------------------
+    def _save(self):
+        self.xr[self.i] = self.f.x.copy()
+        self.Pr[self.i] = self.f.P.copy()
+
+    def _load(self):
+        # the reference ring holds x and P only: feature bookkeeping (len_features_, ids) is not rewound
+        self.f.x[:] = self.xr[self.i]
+        self.f.P[:] = self.Pr[self.i]
+
+    def _rot(self, u):
+        q = np.array(self.f.q_b_u)
+        u = np.asarray(u, dtype=np.float64)
+        return np.concatenate([orc.q_rota(q, u[0:3]), orc.q_rota(q, u[3:6])])
+
+    # -- vi_ekf.cpp:262-318 -------------------------------------------------------------------------------------------
+    def propagate_state(self, u, t, save_input=True):
+        ub = self._rot(u)                                   # :265-267
+        if save_input:
+            self.u.appendleft((t, ub))                      # :269-272  (the ROTATED input is stored)
+        if math.isnan(self.start_t):                        # :274-279
+            self.start_t = t
+            self.t[self.i] = t
+            return
+        dt = t - self.t[self.i]
+        if abs(dt) < 1e-6:                                  # :281-283
+            return
+        if dt < 0:                                          # :285-289
+            self.log.append("propagate backwards")
+            return
+        self._save()                                        # (x_[i_], P_[i_] stay behind as history)
+        self.f.propagate(u, dt)                             # :295-304 (+ fix_depth :311); rotates u itself, like the reference
+        ip = (self.i + 1) % self.H
+        self.t[ip] = t
+        self.i = ip
+        self._save()
+
+    # -- vi_ekf_meas.cpp:130-194 ----------------------------------------------------------------------------------------
+    def add_measurement(self, t, z, mtype, R, active=False, id=-1, depth=math.nan):
+        z = np.atleast_1d(np.asarray(z, dtype=np.float64))
+        if t < self.start_t:                                # :133-134 (false while start_t is NaN)
+            return orc.MEAS_INVALID
+        if np.isnan(z).any():                               # :136-137
+            return orc.MEAS_NAN
+        if mtype == orc.FEAT and id >= 0:                   # :140-147
+            if self.f.global_to_local_feature_id(id) < 0:
+                self.f.init_feature(z, id, depth)
+                self._save()
+                return orc.MEAS_NEW_FEATURE
+        k = 0                                               # :150-156 first entry with z.t < t
+        while k < len(self.zbuf) and not (self.zbuf[k].t < t):
+            k += 1
+        m = _Meas()
+        m.t, m.type, m.z, m.R = t, mtype, z.copy(), np.atleast_2d(np.asarray(R, dtype=np.float64)).copy()
+        m.active, m.id, m.depth, m.handled = bool(active), int(id), depth, False
+        self.zbuf.insert(k, m)                              # :169-175
+        return orc.MEAS_SUCCESS
+
+    def _update(self, m):
+        m.handled = True                                    # :198
+        return self.f.update(m.type, m.z, m.R, m.active, m.id)
+
+    # -- vi_ekf_meas.cpp:6-127 --------------------------------------------------------------------------------------------
+    def handle_measurements(self):
+        gated = []
+        if len(self.zbuf) == 0:                             # :12-13
+            return gated
+        zi = len(self.zbuf) - 1                             # :16-18 oldest unhandled
+        while self.zbuf[zi].handled and zi != 0:
+            zi -= 1
+        if zi == 0 and self.zbuf[zi].handled:               # :21-22
+            return gated
+        if self.zbuf[zi].t > self.u[0][0]:                  # :24-28 measurement from the future
+            return gated
+        ui = 0                                              # :32-38 input just before the measurement
+        while ui != len(self.u):
+            if self.zbuf[zi].t > self.u[ui][0]:
+                break
+            ui += 1
+        if ui == len(self.u) or self.zbuf[zi].t <= self.u[ui][0]:   # :39-43 (u_.end() dereference guarded here)
+            self.log.append("not enough history in input buffer")
+            return gated
+        i = self.H                                          # :46-57 rewind
+        while i > 0:
+            if self.t[(self.i + i) % self.H] <= self.u[ui][0]:
+                self.i = (self.i + i) % self.H
+                break
+            i -= 1
+        if i == 0:                                          # :59-64
+            self.log.append("not enough history in state buffer")
+            del self.zbuf[zi]
+            return gated
+        self._load()
+        if self.t[self.i] > self.zbuf[zi].t or abs(self.t[self.i] - self.u[ui][0]) > 1e-8 or self.u[ui][0] > self.zbuf[zi].t:
+            self.log.append("time history misaligned")      # :67-70
+        ui -= 1                                             # :74
+        while ui != 0:                                      # :75
+            while self.zbuf[zi].t <= self.u[ui][0]:         # :78
+                z = self.zbuf[zi]
+                if self.t[self.i] < z.t:                    # :81-82
+                    self.propagate_state(self.u[ui][1], z.t, False)
+                elif self.t[self.i] > z.t:
+                    self.log.append("can't propagate backwards")
+                if z.handled:                               # :87-95
+                    self.log.append("trying to handle measurement again")
+                else:
+                    res = self._update(z)
+                    self._save()
+                    if res == orc.MEAS_GATED and z.type == orc.FEAT:
+                        gated.append(z.id)
+                if zi != 0:                                 # :97-105
+                    zi -= 1
+                    while self.u[ui][0] < self.zbuf[zi].t and ui != 0:
+                        self.propagate_state(self.u[ui][1], self.u[ui][0], False)
+                        ui -= 1
+                else:                                       # :106-115
+                    while ui != 0:
+                        self.propagate_state(self.u[ui][1], self.u[ui][0], False)
+                        ui -= 1
+                    break
+            else:
+                # the reference's outer `while (u_it != u_.begin())` spins here when the next measurement is newer than this
+                # input; with well-formed queues the inner loop always consumes inputs, so leave as the reference would
+                # after the inner propagates
+                break
+        self.propagate_state(self.u[ui][1], self.u[ui][0], False)   # :118
+        while len(self.zbuf) > self.MH:                     # :121-122
+            self.zbuf.pop()
+        while len(self.u) > self.H:                         # :125-126
+            self.u.pop()
+        return gated
+
+    # -- vi_ekf_feat.cpp:81-142 -----------------------------------------------------------------------------------------
+    def keep_only_features(self, features):
+        features = [int(v) for v in features]
+        ids = list(self.f.feature_ids)
+        remove, overlap = [], 0
+        for gid in ids:
+            if gid in features:
+                if self.f.use_keyframe_reset and gid in self.keyframe_features:
+                    overlap += 1
+            else:
+                remove.append(gid)
+        for gid in remove:
+            self.f.clear_feature(gid)
+        if self.f.use_keyframe_reset and len(self.keyframe_features) > 0 and \
+                overlap / float(len(self.keyframe_features)) < self.kf_thresh:
+            self.keyframe_edges.append(self.f.keyframe_reset_edge())
+            self.keyframe_features = list(features)
+        elif self.f.use_keyframe_reset and len(self.keyframe_features) == 0:
+            self.keyframe_features = list(features)
+        self._save()

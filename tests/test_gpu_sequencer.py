@@ -1,0 +1,101 @@
+"""Host sequencer (viekf_seq_*) on the device core vs the line-by-line restatement of the reference's plumbing
+(oracle/seq_oracle.py): delayed measurements, rewind / replay, new features, keyframe trigger.  SURVEY 8(f)-1 / config 1."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import seq_oracle as so
+from tests.test_gpu_parity import assert_close
+
+
+def _params(seed, identity_qbu=False):
+    p = dict(orc.EKF_YAML)
+    if identity_qbu:
+        p["q_b_u"] = [1.0, 0.0, 0.0, 0.0]
+    return p
+
+
+def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64):
+    import vi_ekf_amd as v
+    p = _params(seed, identity_qbu)
+    g = v.BatchVIEKF(B, N, dict(p, keyframe_overlap_threshold=0.8, name="seq"))
+    sg = v.SeqVIEKF(g, state_hist=hist, meas_hist=200)
+    os_ = [so.SeqOracle(orc.OracleFilter(N).init(**p), 0.8, state_hist=hist) for _ in range(B)]
+    rng = np.random.default_rng(seed)
+    pix = rng.uniform(120, 480, (B, N, 2))
+    R = np.eye(2) * 10.0
+    gated_g = [[] for _ in range(B)]
+    gated_o = [[] for _ in range(B)]
+    for k in range(steps):
+        t = 0.004 * k
+        u = np.tile(np.array([0, 0, -9.80665, 0, 0, 0.0]), (B, 1)) + rng.normal(0, 0.3, (B, 6)) * np.array([1, 1, 1, .05, .05, .05])
+        sg.propagate_state(u, t)
+        for b in range(B):
+            os_[b].propagate_state(u[b], t)
+        if k % 7 == 3:   # a camera frame, time-stamped `delay` seconds ago: FEAT for every feature + an altimeter reading
+            tz = t - delay
+            for i in range(N):
+                z = pix[:, i, :] + rng.normal(0, 0.5, (B, 2))
+                if nan_filter is not None and i == 1 and k > 20:
+                    z[nan_filter, 0] = np.nan
+                rg = sg.add_measurement(tz, z, orc.FEAT, R, True, id=i)
+                for b in range(B):
+                    ro = os_[b].add_measurement(tz, z[b], orc.FEAT, R, True, i, float("nan"))
+                    assert rg[b] == ro, (k, i, b, rg[b], ro)
+            alt = rng.normal(2.0, 0.05, (B, 1))
+            sg.add_measurement(tz + 0.001, alt, orc.ALT, np.array([[0.01]]), True)
+            for b in range(B):
+                os_[b].add_measurement(tz + 0.001, alt[b], orc.ALT, np.array([[0.01]]), True)
+            gg = sg.handle_measurements()
+            for b in range(B):
+                gated_g[b] += gg[b]
+                gated_o[b] += os_[b].handle_measurements()
+    return g, sg, os_, gated_g, gated_o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delay", [0.0, 0.0105, 0.03])
+def test_sequencer_matches_reference_plumbing(delay):
+    B, N = 3, 6
+    g, sg, os_, gg, go = _run(B, N, seed=3, delay=delay)
+    x = g.get_state()
+    P = g.get_covariance()
+    for b in range(B):
+        assert sg.tracked_features()[b] == list(os_[b].f.feature_ids)
+        assert not os_[b].log, os_[b].log
+    assert_close(x, np.stack([o.f.x for o in os_]), "x")
+    assert_close(P, np.stack([o.f.P for o in os_]), "P")
+    assert gg == go
+    st = sg.status()
+    assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
+    assert st["queued"] == len(os_[0].zbuf) and st["inputs"] == len(os_[0].u)
+
+
+@pytest.mark.gpu
+def test_sequencer_lockstep_with_a_skipping_filter():
+    """one filter drops a measurement (NaN pixel): with q_b_u = identity the lockstep replay is exact for everybody"""
+    B, N = 3, 5
+    g, sg, os_, gg, go = _run(B, N, seed=5, delay=0.0105, identity_qbu=True, nan_filter=1)
+    assert_close(g.get_state(), np.stack([o.f.x for o in os_]), "x")
+    assert_close(g.get_covariance(), np.stack([o.f.P for o in os_]), "P")
+
+
+@pytest.mark.gpu
+def test_sequencer_keep_only_features_and_keyframe_reset():
+    B, N = 2, 6
+    g, sg, os_, _, _ = _run(B, N, seed=7, delay=0.0, steps=30)
+    keep1 = np.array([[0, 1, 2, 3, 4, 5]] * B)          # first call only records the keyframe features
+    did, _ = sg.keep_only_features(keep1)
+    for b in range(B):
+        os_[b].keep_only_features(keep1[b])
+    assert not did.any()
+    keep2 = np.array([[0, 2, 5, -1, -1, -1]] * B)        # 3 of 6 overlap < 0.8 -> drop 1,3,4 and reset
+    did, edges = sg.keep_only_features(keep2)
+    for b in range(B):
+        os_[b].keep_only_features([0, 2, 5])
+    assert did.all()
+    for b in range(B):
+        assert sg.tracked_features()[b] == list(os_[b].f.feature_ids) == [0, 2, 5]
+        assert_close(edges[b], os_[b].keyframe_edges[-1], "edge")
+    assert_close(g.get_state(), np.stack([o.f.x for o in os_]), "x")
+    assert_close(g.get_covariance(), np.stack([o.f.P for o in os_]), "P")

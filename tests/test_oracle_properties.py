@@ -210,3 +210,37 @@ def test_kf_reset(N):
         assert np.abs(a[0:3, 0:3] - d[0:3, 0:3]).max() <= 1e-3
         assert np.abs(a[6:9, 6:9] - d[6:9, 6:9]).max() <= 1e-1
     assert np.abs(a - d).max() <= 1e-1
+
+
+def test_seq_oracle_delayed_measurement_equals_in_order_when_input_is_unrotated():
+    """host-plumbing restatement (oracle/seq_oracle.py): with q_b_u = identity the rewind/replay of a delayed measurement
+    reproduces the filter that received the same measurement in order (the reference's replay rotates the stored, already
+    rotated input a second time -- vi_ekf.cpp:265-271 -- so the two differ for a non-trivial q_b_u)."""
+    from oracle import seq_oracle as so
+    p = dict(orc.EKF_YAML)
+    p["q_b_u"] = [1.0, 0.0, 0.0, 0.0]
+    N = 3
+    rng = np.random.default_rng(2)
+    pix = rng.uniform(150, 450, (N, 2))
+    us = [np.array([0, 0, -9.80665, 0, 0, 0.0]) + rng.normal(0, 0.2, 6) for _ in range(30)]
+    zs = {k: pix + rng.normal(0, 0.5, (N, 2)) for k in range(40)}
+    R = np.eye(2) * 10.0
+
+    def run(delay_steps):
+        s = so.SeqOracle(orc.OracleFilter(N).init(**p), 0.8, state_hist=32)
+        for k in range(33):
+            s.propagate_state(us[k % 30], 0.004 * k)
+            if k == 0:                        # features are initialised at the state of their first arrival: same in both runs
+                for i in range(N):
+                    assert s.add_measurement(0.0, pix[i], orc.FEAT, R, True, i, float("nan")) == orc.MEAS_NEW_FEATURE
+            kk = k - delay_steps
+            if kk >= 1 and kk % 5 == 2:      # the frame taken at step kk arrives delay_steps later
+                for i in range(N):
+                    s.add_measurement(0.004 * kk, zs[kk][i], orc.FEAT, R, True, i, float("nan"))
+                s.handle_measurements()
+        assert not s.log, s.log
+        return s
+
+    a, b = run(0), run(3)
+    assert a.f.len_features == b.f.len_features == N
+    assert np.abs(a.f.x - b.f.x).max() < 1e-9 and np.abs(a.f.P - b.f.P).max() < 1e-9

@@ -6,3 +6,4 @@ does not need a GPU; using it does, and there is no CPU fallback.
 from . import capi, scene  # noqa: F401
 from .batch import BatchVIEKF  # noqa: F401
 from .capi import Params, ViekfError, device_count, load_yaml  # noqa: F401
+from .seq import SeqVIEKF  # noqa: E402,F401

@@ -396,6 +396,12 @@ int viekf_batch_dims(const viekf_batch* b, int32_t* batch, int32_t* num_features
   return VIEKF_OK;
 }
 
+int viekf_batch_get_params(const viekf_batch* b, viekf_params* out) {
+  if (!b || !out) return fail(VIEKF_ERR_INVALID, "null argument");
+  *out = b->params;
+  return VIEKF_OK;
+}
+
 int viekf_batch_set_stream(viekf_batch* b, void* hip_stream) {
   if (int rc = check_batch(b)) return rc;
   HIP_TRY(hipSetDevice(b->device));

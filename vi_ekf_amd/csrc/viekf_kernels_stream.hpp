@@ -500,6 +500,7 @@ __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, in
   const int slot = slot_all ? slot_all[b] : 0;
   const bool active = active_all ? active_all[b] != 0 : true;
   int* res_out = result_all ? &result_all[b] : nullptr;
+  if (active_all && active_all[b] == 2) { if (res_out && tid == 0) *res_out = -1; return; }   // this filter skips the call
   unsigned flag = 0;
   const bool needs_slot = type == MT_QZETA || type == MT_FEAT || type == MT_DEPTH || type == MT_INV_DEPTH;
   if (needs_slot && (slot < 0 || slot >= len)) { if (res_out && tid == 0) *res_out = (slot < 0) ? -1 : 3; return; }

@@ -1,0 +1,337 @@
+// viekf_seq.cpp -- host sequencer over a viekf_batch (include/viekf.h, "Host sequencer"): the reference's input deque,
+// measurement queue, state-history ring with rewind / replay, global feature ids and the keyframe trigger, batched for
+// filters that share one clock.  Uses only the public C ABI of the batch; every numeric operation runs on the device.
+//
+// Reference lines followed (byu-magicc/VI-EKF): src/vi_ekf/vi_ekf.cpp:262-318 (propagate_state bookkeeping),
+// src/vi_ekf/vi_ekf_meas.cpp:6-127 (handle_measurements), :130-194 (add_measurement), src/vi_ekf/vi_ekf_feat.cpp:29-30,
+// 81-142 (feature numbering, keep_only_features), src/vi_ekf/vi_ekf_helper.cpp:114-125 (global_to_local_feature_id).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/viekf.h"
+
+namespace {
+
+struct SeqMeas {                      // measurement_t, include/vi_ekf.h:167-179 (per-filter payload for the whole batch)
+  double t;
+  int type, zdim, rdim;
+  std::vector<double> z;              // [B][zdim]
+  std::vector<double> R;              // rdim x rdim
+  bool active;
+  std::vector<int32_t> id;            // [B] global feature id
+  std::vector<uint8_t> present;       // [B] this filter queued the entry
+  bool handled;
+};
+
+void rota(const double* q, const double* v, double* o) {   // src/quat.cpp:279-283
+  const double* b = q + 1;
+  double t[3] = {2.0 * (b[1] * v[2] - b[2] * v[1]), 2.0 * (b[2] * v[0] - b[0] * v[2]), 2.0 * (b[0] * v[1] - b[1] * v[0])};
+  double c[3] = {b[1] * t[2] - b[2] * t[1], b[2] * t[0] - b[0] * t[2], b[0] * t[1] - b[1] * t[0]};
+  for (int i = 0; i < 3; i++) o[i] = v[i] + q[0] * t[i] + c[i];
+}
+
+}  // namespace
+
+struct viekf_seq {
+  viekf_batch* core = nullptr;
+  int B = 0, N = 0, H = 0, MH = 0;
+  viekf_params prm;
+  std::vector<double> t;                                           // t_ ring
+  int i = 0;                                                       // i_
+  bool dirty = true;                                               // live state not yet saved in ring slot i
+  double start_t = NAN;
+  std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [B][6]), newest first
+  std::deque<SeqMeas> zbuf;                                        // newest first
+  std::vector<std::vector<int32_t>> ids;                           // current_feature_ids_ per filter
+  std::vector<int32_t> next_id;                                    // next_feature_id_ per filter
+  std::vector<std::vector<int32_t>> kf_feats;                      // keyframe_features_ per filter
+  std::string err;
+};
+
+namespace {
+
+int local_id(const viekf_seq* s, int b, int gid) {                 // vi_ekf_helper.cpp:114-125
+  const auto& v = s->ids[b];
+  auto it = std::find(v.begin(), v.end(), gid);
+  return it == v.end() ? -1 : (int)(it - v.begin());
+}
+
+int set_len(viekf_seq* s) {                                        // feature counts are host bookkeeping (not rewound)
+  std::vector<int32_t> len(s->B);
+  for (int b = 0; b < s->B; b++) len[b] = (int32_t)s->ids[b].size();
+  return viekf_batch_set_state(s->core, nullptr, nullptr, len.data(), VIEKF_HOST);
+}
+
+// numeric core of propagate_state (vi_ekf.cpp:291-311) with ring bookkeeping; `u` is what the caller hands to
+// propagate_state (the batch rotates it by q_b_u itself, :265-267)
+int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
+  const int B = s->B;
+  if (save_input) {
+    std::vector<double> ub((size_t)B * 6);
+    for (int b = 0; b < B; b++) {
+      rota(s->prm.q_b_u, u + 6 * b, ub.data() + 6 * b);
+      rota(s->prm.q_b_u, u + 6 * b + 3, ub.data() + 6 * b + 3);
+    }
+    s->u.emplace_front(t, std::move(ub));                          // :269-272 (the ROTATED input is stored)
+  }
+  if (std::isnan(s->start_t)) {                                    // :274-279
+    s->start_t = t;
+    s->t[s->i] = t;
+    return VIEKF_OK;
+  }
+  const double dt = t - s->t[s->i];
+  if (std::fabs(dt) < 1e-6) return VIEKF_OK;                       // :281-283
+  if (dt < 0) return VIEKF_OK;                                     // :285-289 ("I won't let you")
+  if (s->dirty)                                                    // x_[i_], P_[i_] stay behind as history
+    if (int rc = viekf_batch_snapshot(s->core, s->i)) return rc;
+  std::vector<double> dts((size_t)B, dt);
+  if (int rc = viekf_batch_propagate(s->core, u, dts.data(), VIEKF_HOST)) return rc;
+  s->i = (s->i + 1) % s->H;                                        // :298,306
+  s->t[s->i] = t;
+  s->dirty = true;
+  return VIEKF_OK;
+}
+
+int update_entry(viekf_seq* s, SeqMeas& m, std::vector<int32_t>& res) {   // VIEKF::update, vi_ekf_meas.cpp:196-278
+  const int B = s->B;
+  m.handled = true;                                                // :198
+  res.assign(B, VIEKF_MEAS_SKIPPED);
+  std::vector<int32_t> slot(B, -1);
+  const bool needs_slot = m.type == VIEKF_QZETA || m.type == VIEKF_FEAT || m.type == VIEKF_DEPTH || m.type == VIEKF_INV_DEPTH;
+  std::vector<uint8_t> act(B);
+  for (int b = 0; b < B; b++) {
+    if (needs_slot) slot[b] = m.present[b] ? local_id(s, b, m.id[b]) : -1;
+    act[b] = m.present[b] ? (m.active ? 1 : 0) : 2;                // 2 = this filter skips the entry altogether
+  }
+  int rc;
+  if (m.type == VIEKF_FEAT && m.active) {
+    rc = viekf_batch_update_feat(s->core, m.z.data(), slot.data(), 1, m.R.data(), 0, res.data(), VIEKF_HOST);
+  } else {
+    rc = viekf_batch_update(s->core, m.type, m.z.data(), m.zdim, m.R.data(), m.rdim, 0, needs_slot ? slot.data() : nullptr,
+                            act.data(), res.data(), VIEKF_HOST);
+  }
+  s->dirty = true;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, viekf_seq** out) {
+  if (!core || !out || state_hist < 2 || meas_hist < 1) return VIEKF_ERR_INVALID;
+  viekf_seq* s = new viekf_seq;
+  s->core = core;
+  int32_t B, N, nx, n;
+  if (int rc = viekf_batch_dims(core, &B, &N, &nx, &n)) { delete s; return rc; }
+  if (int rc = viekf_batch_get_params(core, &s->prm)) { delete s; return rc; }
+  if (int rc = viekf_batch_history_resize(core, state_hist)) { delete s; return rc; }
+  s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
+  s->t.assign(state_hist, NAN);                                    // vi_ekf.cpp:22-27
+  s->ids.assign(B, {});
+  s->next_id.assign(B, 0);
+  s->kf_feats.assign(B, {});
+  *out = s;
+  return VIEKF_OK;
+}
+
+int viekf_seq_destroy(viekf_seq* s) {
+  delete s;
+  return VIEKF_OK;
+}
+
+int viekf_seq_propagate(viekf_seq* s, const double* u, double t) {
+  if (!s || !u) return VIEKF_ERR_INVALID;
+  return propagate_core(s, u, t, true);
+}
+
+int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double* z, int32_t zdim, const double* R,
+                              int32_t rdim, int32_t active, const int32_t* id, const double* depth, int32_t* result) {
+  if (!s || !z || !R || zdim < 1 || zdim > 4 || rdim < 1 || rdim > 3) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<int32_t> res(B, VIEKF_MEAS_SUCCESS);
+  SeqMeas m;
+  m.t = t; m.type = type; m.zdim = zdim; m.rdim = rdim; m.active = active != 0; m.handled = false;
+  m.z.assign(z, z + (size_t)B * zdim);
+  m.R.assign(R, R + (size_t)rdim * rdim);
+  m.id.assign(B, -1);
+  m.present.assign(B, 1);
+  std::vector<uint8_t> newf(B, 0);
+  bool any_new = false, any_present = false;
+  for (int b = 0; b < B; b++) {
+    if (id) m.id[b] = id[b];
+    if (t < s->start_t) { res[b] = VIEKF_MEAS_INVALID; m.present[b] = 0; continue; }   // :133-134
+    bool isnan_ = false;
+    for (int k = 0; k < zdim; k++) isnan_ |= std::isnan(z[(size_t)b * zdim + k]);
+    if (isnan_) { res[b] = VIEKF_MEAS_NAN; m.present[b] = 0; continue; }               // :136-137
+    if (type == VIEKF_FEAT && m.id[b] >= 0 && local_id(s, b, m.id[b]) < 0) {           // :140-147
+      res[b] = VIEKF_MEAS_NEW_FEATURE;
+      m.present[b] = 0;
+      if ((int)s->ids[b].size() < s->N) { newf[b] = 1; any_new = true; }              // vi_ekf_feat.cpp:9-10
+      continue;
+    }
+    any_present = true;
+  }
+  if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
+    std::vector<double> dep(B, NAN);
+    if (depth) dep.assign(depth, depth + B);
+    std::vector<int32_t> ok(B, 0);
+    if (int rc = viekf_batch_init_feature(s->core, z, dep.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
+    for (int b = 0; b < B; b++)
+      if (newf[b] && ok[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+    s->dirty = true;
+  }
+  if (any_present) {
+    size_t k = 0;                                                                      // :150-156
+    while (k < s->zbuf.size() && !(s->zbuf[k].t < t)) k++;
+    s->zbuf.insert(s->zbuf.begin() + (long)k, std::move(m));                           // :169-175
+  }
+  if (result) std::memcpy(result, res.data(), sizeof(int32_t) * B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap, int32_t* gated_count) {
+  if (!s) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<std::vector<int32_t>> gated(B);
+  auto finish = [&]() {
+    if (gated_count) for (int b = 0; b < B; b++) gated_count[b] = (int32_t)gated[b].size();
+    if (gated_ids && cap > 0)
+      for (int b = 0; b < B; b++)
+        for (int k = 0; k < cap; k++) gated_ids[(size_t)b * cap + k] = k < (int)gated[b].size() ? gated[b][k] : -1;
+    return VIEKF_OK;
+  };
+  if (s->zbuf.empty() || s->u.empty()) return finish();            // :12-13
+  long zi = (long)s->zbuf.size() - 1;                              // :16-18 oldest unhandled
+  while (s->zbuf[zi].handled && zi != 0) zi--;
+  if (zi == 0 && s->zbuf[zi].handled) return finish();             // :21-22
+  if (s->zbuf[zi].t > s->u[0].first) return finish();              // :24-28 from the future
+  size_t ui = 0;                                                   // :32-38 input just before the measurement
+  while (ui != s->u.size()) {
+    if (s->zbuf[zi].t > s->u[ui].first) break;
+    ui++;
+  }
+  if (ui == s->u.size() || s->zbuf[zi].t <= s->u[ui].first) return finish();   // :39-43 not enough input history
+  int k = s->H, target = -1;                                       // :46-57 rewind
+  while (k > 0) {
+    const int j = (s->i + k) % s->H;
+    if (s->t[j] <= s->u[ui].first) { target = j; break; }
+    k--;
+  }
+  if (k == 0) {                                                    // :59-64 not enough state history
+    s->zbuf.erase(s->zbuf.begin() + zi);
+    return finish();
+  }
+  if (target != s->i) {
+    if (int rc = viekf_batch_restore(s->core, target)) return rc;  // x, P of the slot ...
+    if (int rc = set_len(s)) return rc;                            // ... the feature count is not part of the reference ring
+    s->i = target;
+    s->dirty = false;
+  }
+  std::vector<int32_t> res;
+  ui--;                                                            // :74
+  while (ui != 0) {                                                // :75
+    bool left_inner_by_break = false;
+    while (s->zbuf[zi].t <= s->u[ui].first) {                      // :78
+      SeqMeas& z = s->zbuf[zi];
+      if (s->t[s->i] < z.t)                                        // :81-82
+        if (int rc = propagate_core(s, s->u[ui].second.data(), z.t, false)) return rc;
+      if (!z.handled) {                                            // :87-95
+        if (int rc = update_entry(s, z, res)) return rc;
+        if (z.type == VIEKF_FEAT)
+          for (int b = 0; b < B; b++)
+            if (res[b] == VIEKF_MEAS_GATED) gated[b].push_back(z.id[b]);
+      }
+      if (zi != 0) {                                               // :97-105
+        zi--;
+        while (s->u[ui].first < s->zbuf[zi].t && ui != 0) {
+          if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;
+          ui--;
+        }
+      } else {                                                     // :106-115
+        while (ui != 0) {
+          if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;
+          ui--;
+        }
+        left_inner_by_break = true;
+        break;
+      }
+    }
+    if (!left_inner_by_break) break;   // (the inner condition can only fail with ui == 0)
+  }
+  if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;   // :118
+  while ((int)s->zbuf.size() > s->MH) s->zbuf.pop_back();          // :121-122
+  while ((int)s->u.size() > s->H) s->u.pop_back();                 // :125-126
+  return finish();
+}
+
+int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count, uint8_t* did_reset, double* edges) {
+  if (!s || (count > 0 && !ids) || count < 0) return VIEKF_ERR_INVALID;
+  const int B = s->B, N = s->N;
+  std::vector<uint8_t> keep((size_t)B * N, 0), reset(B, 0);
+  bool any_drop = false, any_reset = false;
+  const bool use_kf = s->prm.use_keyframe_reset != 0;
+  for (int b = 0; b < B; b++) {
+    std::vector<int32_t> want;
+    for (int k = 0; k < count; k++)
+      if (ids[(size_t)b * count + k] >= 0) want.push_back(ids[(size_t)b * count + k]);
+    int overlap = 0;
+    std::vector<int32_t> kept;
+    for (size_t l = 0; l < s->ids[b].size(); l++) {                // vi_ekf_feat.cpp:85-113
+      const int gid = s->ids[b][l];
+      if (std::find(want.begin(), want.end(), gid) != want.end()) {
+        keep[(size_t)b * N + l] = 1;
+        kept.push_back(gid);
+        if (use_kf && std::find(s->kf_feats[b].begin(), s->kf_feats[b].end(), gid) != s->kf_feats[b].end()) overlap++;
+      } else {
+        any_drop = true;
+      }
+    }
+    s->ids[b] = kept;
+    if (use_kf && !s->kf_feats[b].empty() &&
+        (double)overlap / (double)s->kf_feats[b].size() < s->prm.keyframe_overlap_threshold) {   // :119-130
+      reset[b] = 1;
+      any_reset = true;
+      s->kf_feats[b] = want;
+    } else if (use_kf && s->kf_feats[b].empty()) {                 // :131-139
+      s->kf_feats[b] = want;
+    }
+  }
+  if (any_drop) {
+    if (int rc = viekf_batch_keep_features(s->core, keep.data(), nullptr, VIEKF_HOST)) return rc;
+    s->dirty = true;
+  }
+  if (edges) std::memset(edges, 0, sizeof(double) * 17 * (size_t)B);
+  if (any_reset) {
+    if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), edges, VIEKF_HOST)) return rc;
+    s->dirty = true;
+  }
+  if (did_reset) std::memcpy(did_reset, reset.data(), B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_tracked_features(viekf_seq* s, int32_t* ids, int32_t* len) {
+  if (!s) return VIEKF_ERR_INVALID;
+  for (int b = 0; b < s->B; b++) {
+    if (len) len[b] = (int32_t)s->ids[b].size();
+    if (ids)
+      for (int k = 0; k < s->N; k++) ids[(size_t)b * s->N + k] = k < (int)s->ids[b].size() ? s->ids[b][k] : -1;
+  }
+  return VIEKF_OK;
+}
+
+int viekf_seq_status(viekf_seq* s, double* t_now, int32_t* ring_index, int32_t* queued, int32_t* inputs) {
+  if (!s) return VIEKF_ERR_INVALID;
+  if (t_now) *t_now = s->t[s->i];
+  if (ring_index) *ring_index = s->i;
+  if (queued) *queued = (int32_t)s->zbuf.size();
+  if (inputs) *inputs = (int32_t)s->u.size();
+  return VIEKF_OK;
+}
+
+}  // extern "C"

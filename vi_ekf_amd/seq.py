@@ -1,0 +1,93 @@
+"""Python face of the host sequencer (include/viekf.h, viekf_seq_*): the reference's add_measurement /
+handle_measurements / propagate_state / keep_only_features plumbing for a batch of filters that share one clock.
+Plumbing only -- the logic lives in libviekf_hip.so (csrc/viekf_seq.cpp)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _bind():
+    L = capi.lib()
+    if getattr(L, "_seq_bound", False):
+        return L
+    vp = C.c_void_p
+    L.viekf_seq_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.viekf_seq_destroy.argtypes = [vp]
+    L.viekf_seq_propagate.argtypes = [vp, vp, C.c_double]
+    L.viekf_seq_add_measurement.argtypes = [vp, C.c_double, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.viekf_seq_handle_measurements.argtypes = [vp, vp, C.c_int32, vp]
+    L.viekf_seq_keep_only_features.argtypes = [vp, vp, C.c_int32, vp, vp]
+    L.viekf_seq_tracked_features.argtypes = [vp, vp, vp]
+    L.viekf_seq_status.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L._seq_bound = True
+    return L
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class SeqVIEKF:
+    """mirrors vi_ekf::VIEKF's measurement plumbing (reference include/vi_ekf.h:302-308) over a BatchVIEKF"""
+
+    def __init__(self, batch, state_hist=250, meas_hist=200):
+        self.core = batch
+        self.B, self.N = batch.B, batch.N
+        self._L = _bind()
+        h = C.c_void_p()
+        capi.check(self._L.viekf_seq_create(batch._h, int(state_hist), int(meas_hist), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.viekf_seq_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def propagate_state(self, u, t):
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.B, 6)
+        capi.check(self._L.viekf_seq_propagate(self._h, _p(u), float(t)))
+
+    def add_measurement(self, t, z, mtype, R, active=False, id=None, depth=None):
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(self.B, -1)
+        R = np.asfortranarray(np.atleast_2d(np.asarray(R, dtype=np.float64)))
+        Rf = np.ascontiguousarray(R.ravel(order="F"))
+        idp = dp = None
+        if id is not None:
+            ida = np.ascontiguousarray(np.broadcast_to(np.asarray(id, dtype=np.int32), (self.B,)))
+            idp = _p(ida)
+        if depth is not None:
+            da = np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float64), (self.B,)))
+            dp = _p(da)
+        res = np.zeros(self.B, dtype=np.int32)
+        capi.check(self._L.viekf_seq_add_measurement(self._h, float(t), int(mtype), _p(z), z.shape[1], _p(Rf), R.shape[0],
+                                                     int(bool(active)), idp, dp, _p(res)))
+        return res
+
+    def handle_measurements(self, cap=64):
+        ids = np.full((self.B, cap), -1, dtype=np.int32)
+        cnt = np.zeros(self.B, dtype=np.int32)
+        capi.check(self._L.viekf_seq_handle_measurements(self._h, _p(ids), cap, _p(cnt)))
+        return [ids[b, :cnt[b]].tolist() for b in range(self.B)]
+
+    def keep_only_features(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(self.B, -1)
+        did = np.zeros(self.B, dtype=np.uint8)
+        edges = np.zeros((self.B, 17), dtype=np.float64)
+        capi.check(self._L.viekf_seq_keep_only_features(self._h, _p(ids), ids.shape[1], _p(did), _p(edges)))
+        return did, edges
+
+    def tracked_features(self):
+        ids = np.zeros((self.B, self.N), dtype=np.int32)
+        ln = np.zeros(self.B, dtype=np.int32)
+        capi.check(self._L.viekf_seq_tracked_features(self._h, _p(ids), _p(ln)))
+        return [ids[b, :ln[b]].tolist() for b in range(self.B)]
+
+    def status(self):
+        t, i, q, u = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(self._L.viekf_seq_status(self._h, C.byref(t), C.byref(i), C.byref(q), C.byref(u)))
+        return dict(t=t.value, ring_index=i.value, queued=q.value, inputs=u.value)
