@@ -162,6 +162,13 @@ int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge
 int viekf_batch_history_resize(viekf_batch *b, int32_t depth);
 int viekf_batch_snapshot(viekf_batch *b, int32_t slot);
 int viekf_batch_restore(viekf_batch *b, int32_t slot);
+/* Zero-copy use of the ring, as the reference uses its own (x_[i_], P_[i_] ARE the live state, include/vi_ekf.h:156-160):
+ * select makes a slot the live state without copying (slot -1: back to the batch's own buffers); every later call works in
+ * that slot.  propagate_to is viekf_batch_propagate whose result lands in slot dst (src/vi_ekf/vi_ekf.cpp:298-306: x_[ip],
+ * P_[ip] written from x_[i_], P_[i_]) and which then selects dst: the fused kernel reads P from the old slot and stores
+ * it into the new one, so keeping the history costs no extra pass over P.  The feature counts are not part of a slot. */
+int viekf_batch_select(viekf_batch *b, int32_t slot);
+int viekf_batch_propagate_to(viekf_batch *b, const double *u, const double *dt, int32_t dst_slot, viekf_mem where);
 
 /* ONE measurement of any model of the reference's table per filter: VIEKF::update with
  * h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, src/vi_ekf/vi_ekf_meas.cpp:196-386.

@@ -107,3 +107,36 @@ def test_keyframe_reset_matches_oracle(N):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after keyframe reset")
     assert_close(edge, ref_edge, "edge")
     assert np.all(g.get_state()[mask == 1, 0:3] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0)])
+def test_propagate_to_ring_slot_equals_in_place(N, kernel):
+    """zero-copy history: propagate_to writes the next ring slot and selects it; the old slot keeps the old state"""
+    import ctypes as C
+    from vi_ekf_amd import capi
+    B = 3
+    sc = scene.make_scene(B, N, 2, seed=13)
+    ga, gb = v.BatchVIEKF(B, N, sc["params"]), v.BatchVIEKF(B, N, sc["params"])
+    for g in (ga, gb):
+        if kernel:
+            g.set_kernel(kernel)
+        for i in range(N):
+            g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+    L = capi.lib()
+    gb.history_resize(3)
+    gb.snapshot(0)
+    capi.check(L.viekf_batch_select(gb._h, 0))
+    x0, P0 = gb.get_state(), gb.get_covariance()
+    u = np.ascontiguousarray(sc["u"][0]); dt = np.ascontiguousarray(sc["dt"])
+    ga.propagate(u, dt)
+    capi.check(L.viekf_batch_propagate_to(gb._h, C.c_void_p(u.ctypes.data), C.c_void_p(dt.ctypes.data), 1, capi.HOST))
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+    ga.update_feat(sc["z"][0], sc["slot"], sc["R"]); gb.update_feat(sc["z"][0], sc["slot"], sc["R"])   # in the new slot
+    assert np.array_equal(ga.get_covariance(), gb.get_covariance())
+    capi.check(L.viekf_batch_select(gb._h, 0))       # rewind without a copy: slot 0 still holds the state before
+    assert np.array_equal(gb.get_state(), x0) and np.array_equal(gb.get_covariance(), P0)
+    capi.check(L.viekf_batch_select(gb._h, 1))
+    assert np.array_equal(ga.get_covariance(), gb.get_covariance())
+    gb.history_resize(0)                            # leaving the ring brings the live state home
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())

@@ -55,6 +55,8 @@ struct viekf_batch {
   DevParams dp;
   DevParams* d_dp = nullptr;
   int hist_depth = 0;
+  int live_slot = -1;        // >= 0: the live (x, P) ARE this slot of the history ring (d_x / d_P point into it)
+  double *home_x = nullptr, *home_P = nullptr;   // the batch's own buffers (live state while live_slot < 0)
   double *h_x = nullptr, *h_P = nullptr;
   int* h_len = nullptr;
 };
@@ -68,6 +70,7 @@ StreamArgs make_args(const viekf_batch* b) {
   a.B = b->B; a.N = b->N; a.nx = b->nx; a.nxs = b->nxs; a.n = b->n; a.ld = b->ld;
   a.ws_stride = b->ws_stride;
   a.dp = b->d_dp;
+  a.x_out = b->d_x; a.P_out = b->d_P;
   return a;
 }
 
@@ -187,8 +190,10 @@ bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family !
 
 // one launch handles at most MCAP measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
-                    const int* d_slot, int M, const double* d_R, int r_mode, int* d_res) {
+                    const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
+                    double* P_out = nullptr) {
   StreamArgs a = make_args(b);
+  if (x_out) { a.x_out = x_out; a.P_out = P_out; }   // (only meaningful for a single-chunk launch)
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
@@ -369,7 +374,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_x, b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len};
+  void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -618,11 +623,21 @@ int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge
   return VIEKF_OK;
 }
 
+static size_t hist_nx(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->nxs; }
+static size_t hist_nP(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->n * b->ld; }
+static double* slot_x(const viekf_batch* b, int slot) { return reinterpret_cast<double*>(reinterpret_cast<char*>(b->h_x) + hist_nx(b) * slot); }
+static double* slot_P(const viekf_batch* b, int slot) { return reinterpret_cast<double*>(reinterpret_cast<char*>(b->h_P) + hist_nP(b) * slot); }
+
 int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
   if (int rc = check_batch(b)) return rc;
   if (depth < 0 || depth > 4096) return fail(VIEKF_ERR_INVALID, "0 <= depth <= 4096");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->live_slot >= 0) {   // the live state lives in the ring: bring it home first
+    HIP_TRY(hipMemcpy(b->home_x, b->d_x, hist_nx(b), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(b->home_P, b->d_P, hist_nP(b), hipMemcpyDeviceToDevice));
+    b->d_x = b->home_x; b->d_P = b->home_P; b->live_slot = -1;
+  }
   if (b->h_x) { HIP_TRY(hipFree(b->h_x)); b->h_x = nullptr; }
   if (b->h_P) { HIP_TRY(hipFree(b->h_P)); b->h_P = nullptr; }
   if (b->h_len) { HIP_TRY(hipFree(b->h_len)); b->h_len = nullptr; }
@@ -639,23 +654,61 @@ static int history_copy(viekf_batch* b, int32_t slot, bool save) {
   if (int rc = check_batch(b)) return rc;
   if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
   HIP_TRY(hipSetDevice(b->device));
-  const size_t nx = sizeof(double) * (size_t)b->B * b->nxs, nP = sizeof(double) * (size_t)b->B * b->n * b->ld,
-               nl = sizeof(int) * (size_t)b->B;
-  char *hx = reinterpret_cast<char*>(b->h_x) + nx * slot, *hP = reinterpret_cast<char*>(b->h_P) + nP * slot,
-       *hl = reinterpret_cast<char*>(b->h_len) + nl * slot;
+  const size_t nl = sizeof(int) * (size_t)b->B;
+  char* hl = reinterpret_cast<char*>(b->h_len) + nl * slot;
+  const bool same = slot == b->live_slot;   // the live state already IS this slot: only the feature counts move
   if (save) {
-    HIP_TRY(hipMemcpyAsync(hx, b->d_x, nx, hipMemcpyDeviceToDevice, b->stream));
-    HIP_TRY(hipMemcpyAsync(hP, b->d_P, nP, hipMemcpyDeviceToDevice, b->stream));
+    if (!same) {
+      HIP_TRY(hipMemcpyAsync(slot_x(b, slot), b->d_x, hist_nx(b), hipMemcpyDeviceToDevice, b->stream));
+      HIP_TRY(hipMemcpyAsync(slot_P(b, slot), b->d_P, hist_nP(b), hipMemcpyDeviceToDevice, b->stream));
+    }
     HIP_TRY(hipMemcpyAsync(hl, b->d_len, nl, hipMemcpyDeviceToDevice, b->stream));
   } else {
-    HIP_TRY(hipMemcpyAsync(b->d_x, hx, nx, hipMemcpyDeviceToDevice, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->d_P, hP, nP, hipMemcpyDeviceToDevice, b->stream));
+    if (!same) {
+      HIP_TRY(hipMemcpyAsync(b->d_x, slot_x(b, slot), hist_nx(b), hipMemcpyDeviceToDevice, b->stream));
+      HIP_TRY(hipMemcpyAsync(b->d_P, slot_P(b, slot), hist_nP(b), hipMemcpyDeviceToDevice, b->stream));
+    }
     HIP_TRY(hipMemcpyAsync(b->d_len, hl, nl, hipMemcpyDeviceToDevice, b->stream));
   }
   return VIEKF_OK;
 }
 int viekf_batch_snapshot(viekf_batch* b, int32_t slot) { return history_copy(b, slot, true); }
 int viekf_batch_restore(viekf_batch* b, int32_t slot) { return history_copy(b, slot, false); }
+
+int viekf_batch_select(viekf_batch* b, int32_t slot) {
+  if (int rc = check_batch(b)) return rc;
+  if (slot < -1 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+  if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
+  b->live_slot = slot;
+  b->d_x = slot < 0 ? b->home_x : slot_x(b, slot);
+  b->d_P = slot < 0 ? b->home_P : slot_P(b, slot);
+  return VIEKF_OK;
+}
+
+int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, int32_t dst_slot, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || !dt) return fail(VIEKF_ERR_INVALID, "u and dt must not be null");
+  if (dst_slot < 0 || dst_slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+  if (dst_slot == b->live_slot) return viekf_batch_propagate(b, u, dt, where);
+  HIP_TRY(hipSetDevice(b->device));
+  const double *d_u = nullptr, *d_dt = nullptr;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B))) return rc;
+  if (int rc = in_ptr(b, u, (size_t)6 * b->B, where, &d_u)) return rc;
+  if (int rc = in_ptr(b, dt, (size_t)b->B, where, &d_dt)) return rc;
+  if (use_resident(b)) {   // the fused kernel loads P from the live slot and stores it into the destination: no copy at all
+    if (int rc = launch_resident(b, true, d_u, d_dt, nullptr, nullptr, 0, nullptr, 0, nullptr, slot_x(b, dst_slot), slot_P(b, dst_slot)))
+      return rc;
+    if (int rc = viekf_batch_select(b, dst_slot)) return rc;
+  } else {                 // streaming family works in place: copy, then propagate the copy
+    HIP_TRY(hipMemcpyAsync(slot_x(b, dst_slot), b->d_x, hist_nx(b), hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(slot_P(b, dst_slot), b->d_P, hist_nP(b), hipMemcpyDeviceToDevice, b->stream));
+    if (int rc = viekf_batch_select(b, dst_slot)) return rc;
+    if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+  }
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
 
 int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zdim, const double* R, int32_t rdim,
                        int32_t r_mode, const int32_t* slot, const uint8_t* active, int32_t* result, viekf_mem where) {

@@ -795,6 +795,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // ---------------- store ----------------
   // (indices re-derived from opaque copies: otherwise the load addresses are kept alive -- spilled -- all kernel long)
   {
+    P = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
     const int tr = opaque(tr_), td = opaque(td_);
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
@@ -1100,8 +1101,9 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   __syncthreads();  // B5
   RES_STAMP(S, lane == 0, 12);
   // ---------------- store x, status ----------------
-  double* xg = a.x + (long)S.b * a.nxs;
-  for (int i = lane; i < xZ + 5 * len; i += 64) {
+  double* xg = a.x_out + (long)S.b * a.nxs;
+  const int xend = (a.x_out != a.x) ? a.nxs : xZ + 5 * len;   // another ring slot gets the whole vector (zeros past the features)
+  for (int i = lane; i < xend; i += 64) {
     const double v = xs[i];
     if (v != v) flag |= FLAG_NAN;
     if (v > 1e6) flag |= FLAG_BLOWUP;

@@ -25,6 +25,8 @@ struct StreamArgs {
   int B, N, nx, nxs, n, ld;
   long ws_stride;
   const DevParams* dp;  // device memory (uniform loads); NOT by value: indexing a by-value kernarg array spills it to scratch
+  double* x_out;        // where the fused-step kernel stores the state / covariance: the same buffers (in place) or another
+  double* P_out;        // slot of the history ring (viekf_batch_propagate_to: the propagate writes the NEXT slot, no copy)
 };
 
 // workspace carve-up (doubles) for one filter

@@ -43,7 +43,6 @@ struct viekf_seq {
   viekf_params prm;
   std::vector<double> t;                                           // t_ ring
   int i = 0;                                                       // i_
-  bool dirty = true;                                               // live state not yet saved in ring slot i
   double start_t = NAN;
   std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [B][6]), newest first
   std::deque<SeqMeas> zbuf;                                        // newest first
@@ -59,12 +58,6 @@ int local_id(const viekf_seq* s, int b, int gid) {                 // vi_ekf_hel
   const auto& v = s->ids[b];
   auto it = std::find(v.begin(), v.end(), gid);
   return it == v.end() ? -1 : (int)(it - v.begin());
-}
-
-int set_len(viekf_seq* s) {                                        // feature counts are host bookkeeping (not rewound)
-  std::vector<int32_t> len(s->B);
-  for (int b = 0; b < s->B; b++) len[b] = (int32_t)s->ids[b].size();
-  return viekf_batch_set_state(s->core, nullptr, nullptr, len.data(), VIEKF_HOST);
 }
 
 // numeric core of propagate_state (vi_ekf.cpp:291-311) with ring bookkeeping; `u` is what the caller hands to
@@ -87,13 +80,11 @@ int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
   const double dt = t - s->t[s->i];
   if (std::fabs(dt) < 1e-6) return VIEKF_OK;                       // :281-283
   if (dt < 0) return VIEKF_OK;                                     // :285-289 ("I won't let you")
-  if (s->dirty)                                                    // x_[i_], P_[i_] stay behind as history
-    if (int rc = viekf_batch_snapshot(s->core, s->i)) return rc;
   std::vector<double> dts((size_t)B, dt);
-  if (int rc = viekf_batch_propagate(s->core, u, dts.data(), VIEKF_HOST)) return rc;
-  s->i = (s->i + 1) % s->H;                                        // :298,306
+  const int ip = (s->i + 1) % s->H;                                // :298: x_[ip], P_[ip] are written from x_[i_], P_[i_] --
+  if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), ip, VIEKF_HOST)) return rc;   // the old slot stays as history
+  s->i = ip;                                                       // :306
   s->t[s->i] = t;
-  s->dirty = true;
   return VIEKF_OK;
 }
 
@@ -115,7 +106,6 @@ int update_entry(viekf_seq* s, SeqMeas& m, std::vector<int32_t>& res) {   // VIE
     rc = viekf_batch_update(s->core, m.type, m.z.data(), m.zdim, m.R.data(), m.rdim, 0, needs_slot ? slot.data() : nullptr,
                             act.data(), res.data(), VIEKF_HOST);
   }
-  s->dirty = true;
   return rc;
 }
 
@@ -131,6 +121,8 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   if (int rc = viekf_batch_dims(core, &B, &N, &nx, &n)) { delete s; return rc; }
   if (int rc = viekf_batch_get_params(core, &s->prm)) { delete s; return rc; }
   if (int rc = viekf_batch_history_resize(core, state_hist)) { delete s; return rc; }
+  if (int rc = viekf_batch_snapshot(core, 0)) { delete s; return rc; }     // the live state moves into ring slot i_ = 0
+  if (int rc = viekf_batch_select(core, 0)) { delete s; return rc; }
   s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
   s->t.assign(state_hist, NAN);                                    // vi_ekf.cpp:22-27
   s->ids.assign(B, {});
@@ -141,6 +133,9 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
 }
 
 int viekf_seq_destroy(viekf_seq* s) {
+  if (s && s->core) {   // hand the live state back to the batch's own buffers
+    (void)viekf_batch_history_resize(s->core, 0);
+  }
   delete s;
   return VIEKF_OK;
 }
@@ -184,8 +179,7 @@ int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double
     if (int rc = viekf_batch_init_feature(s->core, z, dep.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
     for (int b = 0; b < B; b++)
       if (newf[b] && ok[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
-    s->dirty = true;
-  }
+    }
   if (any_present) {
     size_t k = 0;                                                                      // :150-156
     while (k < s->zbuf.size() && !(s->zbuf[k].t < t)) k++;
@@ -227,11 +221,9 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     s->zbuf.erase(s->zbuf.begin() + zi);
     return finish();
   }
-  if (target != s->i) {
-    if (int rc = viekf_batch_restore(s->core, target)) return rc;  // x, P of the slot ...
-    if (int rc = set_len(s)) return rc;                            // ... the feature count is not part of the reference ring
+  if (target != s->i) {   // rewind = the ring slot becomes the live state (:50-52); feature counts are not part of the ring
+    if (int rc = viekf_batch_select(s->core, target)) return rc;
     s->i = target;
-    s->dirty = false;
   }
   std::vector<int32_t> res;
   ui--;                                                            // :74
@@ -304,13 +296,11 @@ int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count
   }
   if (any_drop) {
     if (int rc = viekf_batch_keep_features(s->core, keep.data(), nullptr, VIEKF_HOST)) return rc;
-    s->dirty = true;
-  }
+    }
   if (edges) std::memset(edges, 0, sizeof(double) * 17 * (size_t)B);
   if (any_reset) {
     if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), edges, VIEKF_HOST)) return rc;
-    s->dirty = true;
-  }
+    }
   if (did_reset) std::memcpy(did_reset, reset.data(), B);
   return VIEKF_OK;
 }
