@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--feat", type=int, default=50, help="N_feat")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cadence run (profiling: keeps the kernel statistics to the timed steps)")
     ap.add_argument("--cpu-filters", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=0)
     args = ap.parse_args()
@@ -185,7 +186,7 @@ def main():
     # ---- secondary numbers, outside the contract's timed region: the realistic cadence 25 IMU propagates :
     #      3 camera frames (250 Hz : 30 Hz, params/sim_params.yaml:149,160) -- 22 propagate-only launches + 3 full steps
     cadence = None
-    if world == 1:
+    if world == 1 and not args.no_secondary:
         cyc = 4
         torch.cuda.synchronize()
         tc = time.perf_counter()
