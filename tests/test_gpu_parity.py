@@ -244,3 +244,35 @@ def test_wide_p_streaming_family(N, M):
             assert (res[b] == ref).all()
     assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2)])
+def test_more_measurements_than_one_launch_holds(N, M, kernel):
+    """M > 64 measurements per step (the fused kernel takes 64 per launch: vi_ekf_amd chunks, P makes one extra HBM round
+    trip per chunk), with repeated and skipped (-1) slots, against the oracle applying them one by one"""
+    B = 2
+    sc = scene.make_scene(B, N, 1, seed=300 + N)
+    rng = np.random.default_rng(N + M)
+    slot = rng.integers(-1, N, size=(B, M)).astype(np.int32)
+    z = np.zeros((B, M, 2))
+    for b in range(B):
+        for k in range(M):
+            f = max(int(slot[b, k]), 0)
+            z[b, k] = sc["z"][0][b, list(sc["slot"][b]).index(f)] + rng.normal(0, 0.3, 2)
+    g = make_gpu(sc, B, N, kernel=kernel)
+    res = g.step(sc["u"][0], sc["dt"], z, slot, sc["R"])
+    fs = [orc.OracleFilter(N).init(**oracle_params(sc["params"])) for _ in range(B)]
+    R = np.asarray(sc["R"]).reshape(2, 2)
+    for b in range(B):
+        for i in range(N):
+            fs[b].init_feature(sc["pix"][b, i], i)
+        fs[b].propagate(sc["u"][0][b], float(sc["dt"][b]))
+        for k in range(M):
+            if slot[b, k] >= 0:
+                r = fs[b].update(orc.FEAT, z[b, k], R, True, int(slot[b, k]))
+                assert res[b, k] == r
+            else:
+                assert res[b, k] == -1
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
