@@ -116,26 +116,9 @@ __device__ __forceinline__ void bearing_frame_fast(const double* q, double* t1, 
   z[0] = 2.0 * (xz + wy);        z[1] = 2.0 * (yz - wx);        z[2] = 1.0 - 2.0 * (xx + yy);
 }
 
-// h_feat (vi_ekf_meas.cpp:354-367) with the matrix chain multiplied out.  [zeta]x T_z = [zeta x t1, zeta x t2]
-// (= [t2, -t1] for a unit q_zeta; the cross products are kept so a non-unit q behaves like the reference), and
-// F ((zeta e_z^T)/ez - I) w = (f0 (zeta_x w_z/ez - w_x), f1 (zeta_y w_z/ez - w_y)).  One reciprocal.
-__device__ __forceinline__ void h_feat_fast(const double* qz, const DevParams& p, double* zhat, double* Hb) {
-  double t1[3], t2[3], z[3];
-  bearing_frame_fast(qz, t1, t2, z);
-  const double iez = 1.0 / z[2];
-  const double zx = z[0] * iez, zy = z[1] * iez;
-  zhat[0] = p.focal[0] * zx + p.cam_center[0];
-  zhat[1] = p.focal[1] * zy + p.cam_center[1];
-  double c1[3], c2[3];
-  cross3(z, t1, c1);
-  cross3(z, t2, c2);
-  const double f0 = p.focal[0] * iez, f1 = p.focal[1] * iez;
-  Hb[0] = f0 * (zx * c1[2] - c1[0]);
-  Hb[1] = f0 * (zx * c2[2] - c2[0]);
-  Hb[2] = f1 * (zy * c1[2] - c1[1]);
-  Hb[3] = f1 * (zy * c2[2] - c2[1]);
-}
-
+// h_feat (vi_ekf_meas.cpp:354-367) with the matrix chain multiplied out, from an already computed frame of a UNIT
+// bearing quaternion: [zeta]x T_z = [zeta x t1, zeta x t2] and F ((zeta e_z^T)/ez - I) w = (f0 (zeta_x w_z/ez - w_x),
+// f1 (zeta_y w_z/ez - w_y)); one reciprocal.
 // The same from an already computed frame of a UNIT bearing quaternion: (t1, t2, zeta) is then orthonormal and right-handed,
 // so zeta x t1 = t2 and zeta x t2 = -t1 (for |q|^2 = 1 + e the shortcut is off by O(e) ~ 1e-15, far inside the parity bar).
 __device__ __forceinline__ void h_feat_frame(const double* t1, const double* t2, const double* z, const DevParams& p,
@@ -225,52 +208,25 @@ __device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* 
   }
 }
 
-// state correction of one feature + fix_depth + (optionally) the next measurement's prediction
-__device__ RES_INLINE void res_feature_update(double* xf, bool do_corr, bool do_fix, double d0, double d1, double d2,
-                                                const DevParams* p, double* fixadd_slot, double* fixset_slot,
-                                                double* fixany, unsigned* flag, const double* z_next, double* smw) {
-  if (do_corr) {
-    double qn[4];
-    q_feat_boxplus_fast(xf, d0, d1, qn);
-    xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
-    xf[4] += d2;
+// fix_depth of one feature after the propagate (vi_ekf_helper.cpp:128-156, called at vi_ekf.cpp:311): the state here, the
+// covariance edit through the fix mailbox (applied by the worker that owns the feature's diagonal block)
+__device__ RES_INLINE void res_fix_depth(double* xf, const DevParams* p, double* fixadd_slot, double* fixset_slot,
+                                         double* fixany, unsigned* flag) {
+  double rho = xf[4];
+  const double reset = 1.0 / (2.0 * p->min_depth);
+  if (rho != rho) { rho = reset; *flag |= FLAG_NAN; }
+  if (rho < 0.0) {
+    const double err = reset - rho;
+    *fixadd_slot = err * err;
+    *fixany = 1.0;
+    rho = reset;
+    *flag |= FLAG_NEGDEPTH;
+  } else if (rho > 1e2) {
+    *fixset_slot = 1.0;
+    *fixany = 1.0;
+    rho = reset;
   }
-  if (do_fix) {
-    double rho = xf[4];
-    const double reset = 1.0 / (2.0 * p->min_depth);
-    if (rho != rho) { rho = reset; *flag |= FLAG_NAN; }
-    if (rho < 0.0) {
-      const double err = reset - rho;
-      *fixadd_slot = err * err;
-      *fixany = 1.0;
-      rho = reset;
-      *flag |= FLAG_NEGDEPTH;
-    } else if (rho > 1e2) {
-      *fixset_slot = 1.0;
-      *fixany = 1.0;
-      rho = reset;
-    }
-    xf[4] = rho;
-  }
-  if (z_next) {
-    double zhat[2], Hb[4];
-    h_feat_fast(xf, *p, zhat, Hb);
-    smw[2] = Hb[0]; smw[3] = Hb[1]; smw[4] = Hb[2]; smw[5] = Hb[3];
-    smw[6] = z_next[0] - zhat[0]; smw[7] = z_next[1] - zhat[1];
-  }
-}
-
-__device__ RES_INLINE void res_body_update(double* xs, const double* Kt, const double* lam, bool partial, double r0,
-                                             double r1) {
-  double dxb[16], xo[17];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const double l = partial ? lam[i] : 1.0;
-    dxb[i] = (l * Kt[2 * i]) * r0 + (l * Kt[2 * i + 1]) * r1;
-  }
-  body_boxplus_fast(xs, dxb, xo);
-#pragma unroll
-  for (int i = 0; i < 17; i++) xs[i] = xo[i];
+  xf[4] = rho;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,8 +830,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     }
     if (lane == 0) sm[40 + par] = 0.0;
     for (int f = lane; f < len; f += 64)   // fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
-      res_feature_update(xs + xZ + 5 * f, false, true, 0.0, 0.0, 0.0, a.dp, &S.fixadd[par * N + f],
-                         &S.fixset[par * N + f], &sm[40 + par], &flag, nullptr, nullptr);
+      res_fix_depth(xs + xZ + 5 * f, a.dp, &S.fixadd[par * N + f], &S.fixset[par * N + f], &sm[40 + par], &flag);
     par ^= 1;
     RES_STAMP(S, lane == 0, 6);
     __syncthreads();  // B3p
