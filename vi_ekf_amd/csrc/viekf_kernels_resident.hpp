@@ -31,10 +31,12 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
     Kt = take(2 * n); Wt = take(2 * n);
-    Praw = take(4 * n > 256 ? 4 * n : 256);   // two buffers of [n][2]; doubles as the 16x16 scratch T16 of the propagate
+    Praw = take(4 * n > 256 ? 4 * n : 256);   // [n][2] raw columns of the next measurement, then [2][16][2] stashed body rows;
+                                              // doubles as the 16x16 scratch T16 of the propagate
     lam = take(n);
     sm = take(64);   // [0..15],[16..31] two measurement mailboxes {Hb(4) res(2) Sinv(4) verdict}, [40..41] fix mailboxes
-                     // non-empty, [42] dt, [44..45] NaN-guard words (one per mailbox)
+                     // non-empty, [42] dt, [44..46] NaN-guard words (phase mod 3), [49] count of worker waves that have
+                     // published the next raw columns (int), [50..51] gate verdicts (phase parity)
     Pd = take(4 * (N > 0 ? N : 1));   // zeta-zeta 2x2 diagonal blocks, handed from the workers to the service lanes
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
     X = take(nf * XK); Y = take(nf * XK);
