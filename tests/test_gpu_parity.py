@@ -68,8 +68,8 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
 
 # kernel 1 = streaming family (P in HBM/L2), 2 = resident family (P in registers, N in 8..50)
 @pytest.mark.parametrize("B,N,steps,kernel", [(3, 3, 6, 1), (4, 12, 5, 1), (2, 25, 3, 1), (2, 50, 2, 1),
-                                              (4, 8, 4, 2), (4, 12, 5, 2), (3, 17, 3, 2), (2, 25, 3, 2),
-                                              (2, 33, 2, 2), (2, 41, 2, 2), (3, 50, 2, 2)])
+                                              (3, 1, 4, 2), (3, 2, 4, 2), (4, 8, 4, 2), (4, 12, 5, 2), (3, 17, 3, 2), (2, 25, 3, 2),
+                                              (2, 33, 2, 2), (2, 41, 2, 2), (2, 49, 2, 2), (3, 50, 2, 2)])
 def test_step_parity(B, N, steps, kernel):
     sc = scene.make_scene(B, N, steps, seed=100 + N)
     x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)
