@@ -97,11 +97,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (rehearsals of the N > 1 path on a one-GPU box: VIEKF_DIST_BACKEND=gloo shares the card between the ranks)
+    backend = os.environ.get("VIEKF_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import vi_ekf_amd as v
     from vi_ekf_amd import scene
@@ -115,7 +121,7 @@ def main():
     sc = scene.make_scene(B, N, uniq, seed=0x5EED0000 + rank)
     params = sc["params"]
 
-    g = v.BatchVIEKF(B, N, params, device=local_rank)
+    g = v.BatchVIEKF(B, N, params, device=dev_index)
     if args.kernel:
         g.set_kernel(args.kernel)
     g.use_torch_stream()
