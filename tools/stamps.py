@@ -44,3 +44,7 @@ for w in range(7):
     print("update 3 worker wave %d: phase top -> before B1 %5d | B1 wait %5d   (top skew vs wave 0: %d)" % (
         w, d(q, q + 1), d(q + 1, q + 3), int(t[q] - t[192])))
 print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(62, 73))
+print("store: body cols %d" % d(72, 224))
+for ch in range(3):
+    q = 225 + 4 * ch
+    print("  chunk %d: image writes %5d | S1 wait %5d | copy-out %5d | S2 wait %5d" % (ch, d(q - 1, q), d(q, q + 1), d(q + 1, q + 2), d(q + 2, q + 3)))

@@ -434,6 +434,61 @@ __device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShar
     }
 }
 
+// Store of P, cooperative part.  The workers scatter their 3x3 blocks (and the mirror images) into an LDS image of a chunk of
+// feature columns -- the X/Y region, free after the propagate; [column][n rows] -- and the whole workgroup streams the chunk
+// out with lanes along the rows: every wave instruction writes up to 512 contiguous bytes instead of 64 different cache
+// lines (the direct 8-byte block stores were bound by the texture path's one line per clock: 25 k clk per step).
+// Rows 0..15 of a feature column are the mirror of the LDS-resident body columns.
+struct StoreChunks {
+  int fc, nchunks;   // features per chunk, number of chunks
+  __device__ StoreChunks(int N, int n, int nf) {
+    fc = max(1, min(N, (2 * nf * XK) / (3 * n)));
+    nchunks = (N + fc - 1) / fc;
+  }
+};
+template <int T>
+__device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResShared& S, int f0, int f1, int tid) {
+  const int n = S.n, ld = a.ld;
+  double* P = a.P_out + (long)S.b * n * ld;
+  const double* img = S.X;
+  const int ncol = 3 * (f1 - f0), lane = tid & 63, w = tid >> 6;
+  constexpr int NWV = T / 64;
+  if ((n & 1) == 0) {   // even n: row pairs are 16-byte aligned in the image, in Pbc and in P (ld is even)
+#pragma unroll 4
+    for (int c = w; c < ncol; c += NWV) {
+      const int j = 16 + 3 * f0 + c;
+      double2 v[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = 2 * (lane + 64 * u);
+        const double* src = (i < 16) ? (S.Pbc + (j - 16) * 16 + i) : (img + c * n + min(i, n - 2));
+        v[u] = *reinterpret_cast<const double2*>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = 2 * (lane + 64 * u);
+        if (i < n) *reinterpret_cast<double2*>(P + i + (long)j * ld) = v[u];
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (int c = w; c < ncol; c += NWV) {
+      const int j = 16 + 3 * f0 + c;
+      double v[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int i = lane + 64 * u;
+        v[u] = (i < 16) ? S.Pbc[(j - 16) * 16 + i] : img[c * n + min(i, n - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int i = lane + 64 * u;
+        if (i < n) P[i + (long)j * ld] = v[u];
+      }
+    }
+  }
+}
+
 template <int RB, int TW>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
@@ -754,39 +809,52 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // (indices re-derived from opaque copies: otherwise the load addresses are kept alive -- spilled -- all kernel long)
   {
     P = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
-    const int tr = opaque(tr_), td = opaque(td_);
-#pragma unroll
-    for (int ia = 0; ia < RB; ia++) {
-      int I, J;
-      if (blk(tr, td, ia, I, J)) {
-        double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);   // block (I,J)
-        double* pt = P + ((16 + 3 * J) + (long)(16 + 3 * I) * ld);   // its mirror (J,I)
-#pragma unroll
-        for (int s = 0; s < 3; s++)
-#pragma unroll
-          for (int r = 0; r < 3; r++) pu[r + (long)s * ld] = pb[ia][r * 3 + s];
-        if (I != J) {
-#pragma unroll
-          for (int s = 0; s < 3; s++)
-#pragma unroll
-            for (int r = 0; r < 3; r++) pt[s + (long)r * ld] = pb[ia][r * 3 + s];
-        }
-      }
-    }
     for (int e = opaque(tid); e < nf * 16; e += TW) {     // body columns, coalesced along rows
       const int k = e / nf, row = e - k * nf;
       P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];
     }
-    for (int e = opaque(tid); e < nf * 16; e += TW) {     // mirrored body rows, coalesced along k
-      const int row = e >> 4, k = e & 15;
-      P[k + (long)(16 + row) * ld] = Pbc[e];
-    }
     for (int e = opaque(tid); e < 256; e += TW) P[(e >> 4) + (long)(e & 15) * ld] = Pbb[e];
+    const StoreChunks sc(N, n, nf);
+    double* img = S.X;
+    const int gtid = threadIdx.x;
+    RES_STAMP(S, tid == 0, 224);
+    for (int ch = 0; ch < sc.nchunks; ch++) {
+      const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
+      const int tr = opaque(tr_), td = opaque(td_);
+#pragma unroll
+      for (int ia = 0; ia < RB; ia++) {
+        int I, J;
+        if (blk(tr, td, ia, I, J)) {
+          if (J >= f0 && J < f1) {                          // block (I,J): columns of feature J
+            double* d = img + (3 * (J - f0)) * n + 16 + 3 * I;
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+#pragma unroll
+              for (int r = 0; r < 3; r++) d[s * n + r] = pb[ia][r * 3 + s];
+          }
+          if (I != J && I >= f0 && I < f1) {                // its mirror (J,I): columns of feature I
+            double* d = img + (3 * (I - f0)) * n + 16 + 3 * J;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int s = 0; s < 3; s++) d[r * n + s] = pb[ia][r * 3 + s];
+          }
+        }
+      }
+      RES_STAMP(S, tid == 0 && ch < 3, 225 + 4 * ch);
+      __syncthreads();   // S1: the chunk image is complete
+      RES_STAMP(S, tid == 0 && ch < 3, 226 + 4 * ch);
+      res_store_chunk<TW + 64>(a, S, f0, f1, gtid);
+      RES_STAMP(S, tid == 0 && ch < 3, 227 + 4 * ch);
+      __syncthreads();   // S2: the image may be overwritten
+      RES_STAMP(S, tid == 0 && ch < 3, 228 + 4 * ch);
+    }
   }
   RES_STAMP(S, tid == 0, 73);
 }
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
+template <int T>
 __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane, int nww,
                                             const double* __restrict__ u_all, int* __restrict__ result_all) {
   const int N = S.N, n = S.n, len = S.len, M = S.M;
@@ -1068,6 +1136,15 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   }
   if (flag) atomicOr(&a.flags[S.b], flag);
   RES_STAMP(S, lane == 0, 13);
+  {   // cooperative store of P (see res_store_chunk): this wave streams its share of every chunk
+    const StoreChunks sc(N, n, S.nf);
+    for (int ch = 0; ch < sc.nchunks; ch++) {
+      const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
+      __syncthreads();   // S1
+      res_store_chunk<T>(a, S, f0, f1, threadIdx.x);
+      __syncthreads();   // S2
+    }
+  }
 }
 
 // Common prologue of the fused-step kernels: LDS carve-up, state, lambdas, mailboxes and the measurement table (validity
@@ -1139,7 +1216,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_step_resident(StreamArgs a, i
   // the service wave.  With 8 waves (NW = 7) every SIMD holds two and the last wave serves.
   constexpr int SVC = (NW == 6) ? 3 : NW;
   const int wave = tid >> 6;
-  if (wave == SVC) res_service(a, S, tid & 63, NW, u_all, result_all);
+  if (wave == SVC) res_service<T>(a, S, tid & 63, NW, u_all, result_all);
   else res_worker<RB, TW>(a, S, TR, TD, tid - (wave > SVC ? 64 : 0));
 }
 
