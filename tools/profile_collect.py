@@ -48,6 +48,22 @@ j = {"config": {"batch": 1024, "n_feat": 50, "kernel": "k_step_resident<3,7>"},
              "doubled; the rule is calibrated for 16-B/lane streams, this kernel reads P with 8-B strided loads (uncalibrated "
              "width). WRITE_SIZE is taken as is."}
 json.dump(j, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+sq = {}
+nl = 0
+for sub in ("sq1", "sq2"):
+    try:
+        rows = [r for r in csv.DictReader(open(find(sub, "*counter_collection.csv"))) if "k_step_resident" in r["Kernel_Name"]]
+    except SystemExit:
+        rows = []
+    acc = {}
+    for r in rows:
+        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        sq[k] = sum(v) / len(v)
+        nl = len(v)
+if sq:
+    json.dump({"config": j["config"], "mean_per_launch": sq, "launches": nl}, open(os.path.join(dst, tag + "_pmc_sq.json"), "w"), indent=1)
+    print("SQ:", {k: round(v / 1e6, 1) for k, v in sq.items()}, "(millions per launch)")
 ks = [r for r in csv.DictReader(open(os.path.join(dst, tag + "_kernel_stats.csv"))) if "k_step_resident" in r["Name"]]
 print("kernel avg ns", ks[0]["AverageNs"], "calls", ks[0]["Calls"], " traffic MB %.1f (fetch raw %.1f, write %.1f)" % ((2 * fb + wb) / 1e6, fb / 1e6, wb / 1e6))
 print(open(os.path.join(dst, tag + "_bench.json")).read()[:400])
