@@ -134,8 +134,24 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
-  hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
-                     d_slot, M, d_R, rsb, rsm, d_res);
+  // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass);
+  // VIEKF_STREAM_BLOCKED=0 keeps the one-pass-per-measurement kernel (experiments)
+  static const bool blocked_ok = []() { const char* e = getenv("VIEKF_STREAM_BLOCKED"); return !(e && atoi(e) == 0); }();
+  const BlkLds BL(b->N, b->n, b->nxs);
+  const size_t blds = sizeof(double) * (size_t)BL.total;
+  if (blocked_ok && M >= 2 && blds + 1024 <= 160 * 1024) {   // (+ the kernel's small static LDS)
+    static size_t attr_bytes = 0;
+    if (blds > attr_bytes) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_feat_blocked<512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      attr_bytes = blds;
+    }
+    hipLaunchKernelGGL(k_update_feat_blocked<512>, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb,
+                       rsm, d_res);
+  } else {
+    hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
+                       d_slot, M, d_R, rsb, rsm, d_res);
+  }
   HIP_TRY(hipGetLastError());
   return VIEKF_OK;
 }

@@ -420,6 +420,266 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
 }
 
 // ------------------------------------------------------------------------------------------------
+// M sequential active FEAT updates, BLOCKED for a covariance that does not fit on chip (wide P): the same arithmetic
+// as k_update_feat_stream, but P crosses HBM once per GROUP of up to BG measurements instead of once per measurement.
+//   1. panel:  the 2 zeta columns of every feature measured in the group, all rows, -> LDS  (n x 2 BG)
+//   2. for each measurement of the group, in order: innovation, gate, W = panel_g Hb^T (in place), K = W S^-1, state
+//      correction, fix_depth; the rank-2 update is applied to the LATER panel columns only (they are all that the
+//      following gains need) and to an exact running copy of the rho-rho diagonal (fix_depth edits it, vi_ekf_helper.cpp:
+//      128-156, and a "set" does not commute with later updates).
+//   3. one pass over P:  P -= Lambda o (K W^T)  with K, W = n x 2 BG from LDS -- a dense contraction, done per 16x16 tile by
+//      v_mfma_f64_16x16x4_f64 (4 k-steps), Lambda applied to the accumulator; the rho-rho diagonal takes the running copy.
+// A slot that repeats inside a group starts a new group.  HBM traffic per step drops from (M+1) to (M/BG+1) passes over P.
+// LDS rows of K / W are 18 doubles apart: the MFMA operand reads (16 consecutive rows per k) then hit distinct banks.
+// ------------------------------------------------------------------------------------------------
+constexpr int BG = 8;     // measurements per group
+constexpr int BLD = 18;   // LDS row stride (doubles) of the n x 16 gain arrays
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+struct BlkLds {
+  int xs, lam, Wp, Kb, sm, diag, gsl, total;   // offsets in doubles
+  __host__ __device__ BlkLds(int N, int n, int nxs) {
+    const int nr = (n + 15) & ~15;
+    int o = 0;
+    auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
+    xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Kb = take(nr * BLD); sm = take(32); diag = take(N > 0 ? N : 1);
+    gsl = take(2 * BG);   // ints: slot[BG], measurement index[BG]
+    total = o;
+  }
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const double* __restrict__ z_all,
+                                                           const int* __restrict__ slot_all, int M,
+                                                           const double* __restrict__ R_all, long r_stride_b,
+                                                           long r_stride_m, int* __restrict__ result_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, ld = a.ld;
+  const BlkLds L(a.N, n, a.nxs);
+  double* xs = smem + L.xs;
+  double* lam = smem + L.lam;
+  double* Wp = smem + L.Wp;     // panel of raw columns, turned into W pair by pair
+  double* Kb = smem + L.Kb;
+  double* sm = smem + L.sm;
+  double* diag = smem + L.diag; // running P(rho_f, rho_f)
+  int* gsl = reinterpret_cast<int*>(smem + L.gsl);
+  int* gml = gsl + BG;
+  double* xg = a.x + (long)b * a.nxs;
+  double* P = a.P + (long)b * n * ld;
+  const int len = a.len[b];
+  const int nact = 16 + 3 * len;
+  const DevParams& prm = *a.dp;
+  const bool partial = prm.use_partial_update != 0;
+  unsigned flag = 0;
+  constexpr int NWV = T / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
+  for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
+  __syncthreads();
+
+  int m = 0;
+  while (m < M) {
+    // ---- form the next group (every thread scans the same list: uniform control flow; tid 0 records it)
+    int Gn = 0;
+    {
+      int mm = m;
+      unsigned long long seen_lo = 0, seen_hi = 0;   // slots already in the group (N <= 128 covers the 160-feature limit? no: 3 words)
+      unsigned long long seen_h2 = 0;
+      while (mm < M && Gn < BG) {
+        const int slot = slot_all[(long)b * M + mm];
+        const double z0 = z_all[((long)b * M + mm) * 2], z1 = z_all[((long)b * M + mm) * 2 + 1];
+        int code = 0;
+        if (slot < 0) code = -1;
+        else if (slot >= len) code = 3;                 // MEAS_INVALID
+        else if (z0 != z0 || z1 != z1) code = 2;        // MEAS_NAN (vi_ekf_meas.cpp:136-137)
+        if (code != 0) {
+          if (result_all && tid == 0) result_all[(long)b * M + mm] = code;
+          mm++;
+          continue;
+        }
+        unsigned long long& w = slot < 64 ? seen_lo : (slot < 128 ? seen_hi : seen_h2);
+        const unsigned long long bit = 1ull << (slot & 63);
+        if (w & bit) break;                             // repeated slot: it opens the next group
+        w |= bit;
+        if (tid == 0) { gsl[Gn] = slot; gml[Gn] = mm; }
+        Gn++;
+        mm++;
+      }
+      m = mm;
+    }
+    if (Gn == 0) continue;
+    __syncthreads();
+    // ---- 1. panel <- the zeta columns of the group's features (coalesced along the rows); unused columns <- 0
+    for (int c = 0; c < 2 * BG; c++) {
+      if (c < 2 * Gn) {
+        const int col = 16 + 3 * gsl[c >> 1] + (c & 1);
+        for (int i = tid; i < nact; i += T) Wp[i * BLD + c] = P[i + (long)col * ld];
+      } else {
+        for (int i = tid; i < nact; i += T) { Wp[i * BLD + c] = 0.0; Kb[i * BLD + c] = 0.0; }
+      }
+    }
+    for (int f = tid; f < len; f += T) diag[f] = P[(16 + 3 * f + 2) + (long)(16 + 3 * f + 2) * ld];
+    __syncthreads();
+    // ---- 2. the measurements of the group, in order
+    for (int g = 0; g < Gn; g++) {
+      const int slot = gsl[g], mi = gml[g];
+      int* res = result_all ? &result_all[(long)b * M + mi] : nullptr;
+      const double* R = R_all + (long)b * r_stride_b + (long)mi * r_stride_m;   // column-major 2x2
+      const int j0 = 16 + 3 * slot;
+      if (tid == 0) {
+        double zhat[2], Hb[4];
+        h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
+        sm[2] = Hb[0]; sm[3] = Hb[1]; sm[4] = Hb[2]; sm[5] = Hb[3];
+        sm[6] = z_all[((long)b * M + mi) * 2] - zhat[0];           // residual (vi_ekf_meas.cpp:220)
+        sm[7] = z_all[((long)b * M + mi) * 2 + 1] - zhat[1];
+      }
+      __syncthreads();
+      const double h00 = sm[2], h01 = sm[3], h10 = sm[4], h11 = sm[5], r0 = sm[6], r1 = sm[7];
+      double S[4], Si[4];
+      {   // S = Hb P_zz Hb^T + R from the panel (current columns of this feature), uniform
+        const double p00 = Wp[j0 * BLD + 2 * g], p01 = Wp[j0 * BLD + 2 * g + 1];
+        const double p10 = Wp[(j0 + 1) * BLD + 2 * g], p11 = Wp[(j0 + 1) * BLD + 2 * g + 1];
+        const double w00 = p00 * h00 + p01 * h01, w01 = p00 * h10 + p01 * h11;      // W rows j0, j0+1
+        const double w10 = p10 * h00 + p11 * h01, w11 = p10 * h10 + p11 * h11;
+        S[0] = h00 * w00 + h01 * w10 + R[0];
+        S[1] = h00 * w01 + h01 * w11 + R[2];
+        S[2] = h10 * w00 + h11 * w10 + R[1];
+        S[3] = h10 * w01 + h11 * w11 + R[3];
+      }
+      inv2(S, Si);
+      const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;   // vi_ekf_meas.cpp:234
+      __syncthreads();   // (everyone has read P_zz before the rows below overwrite the pair with W)
+      if (mahal > 9.0) {                                   // gate (:235-239): returns before fix_depth
+        if (res && tid == 0) *res = 1;
+        for (int i = tid; i < nact; i += T) {
+          Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; Kb[i * BLD + 2 * g] = 0.0; Kb[i * BLD + 2 * g + 1] = 0.0;
+        }
+        __syncthreads();
+        continue;
+      }
+      int bad = 0;
+      for (int i = tid; i < nact; i += T) {                // W = P H^T, K = W S^-1 (:241), NaN guard (:247)
+        const double p0 = Wp[i * BLD + 2 * g], p1 = Wp[i * BLD + 2 * g + 1];
+        const double w0 = p0 * h00 + p1 * h01, w1 = p0 * h10 + p1 * h11;
+        const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
+        Wp[i * BLD + 2 * g] = w0; Wp[i * BLD + 2 * g + 1] = w1;
+        Kb[i * BLD + 2 * g] = k0; Kb[i * BLD + 2 * g + 1] = k1;
+        if (k0 != k0 || k1 != k1) bad = 1;
+      }
+      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
+      bad = __syncthreads_or(bad);
+      if (bad) {
+        for (int i = tid; i < nact; i += T) {
+          Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; Kb[i * BLD + 2 * g] = 0.0; Kb[i * BLD + 2 * g + 1] = 0.0;
+        }
+      } else {
+        // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263)
+        if (tid == 0) {
+          double dxb[16], xo[17];
+          for (int i = 0; i < 16; i++) {
+            const double l = partial ? lam[i] : 1.0;
+            dxb[i] = (l * Kb[i * BLD + 2 * g]) * r0 + (l * Kb[i * BLD + 2 * g + 1]) * r1;
+          }
+          body_boxplus(xs, dxb, xo);
+          for (int i = 0; i < 17; i++) xs[i] = xo[i];
+        }
+        for (int f = tid; f < len; f += T) {
+          const int d = 16 + 3 * f;
+          double dv[3];
+          for (int q = 0; q < 3; q++) {
+            const double l = partial ? lam[d + q] : 1.0;
+            dv[q] = (l * Kb[(d + q) * BLD + 2 * g]) * r0 + (l * Kb[(d + q) * BLD + 2 * g + 1]) * r1;
+          }
+          double qn[4];
+          q_feat_boxplus(xs + xZ + 5 * f, dv[0], dv[1], qn);
+          double* xf = xs + xZ + 5 * f;
+          xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
+          xf[4] += dv[2];
+          // running rho-rho diagonal:  P_ii -= Lambda_ii (K_i . W_i)
+          const int ir = d + 2;
+          const double li = lam[ir];
+          const double Lii = partial ? (li + li - li * li) : 1.0;
+          diag[f] -= Lii * (Kb[ir * BLD + 2 * g] * Wp[ir * BLD + 2 * g] + Kb[ir * BLD + 2 * g + 1] * Wp[ir * BLD + 2 * g + 1]);
+        }
+        // the later panel columns follow the update:  P_ic -= Lambda_ic (K_i . W_c)
+        for (int c = 2 * (g + 1); c < 2 * Gn; c++) {
+          const int cr = 16 + 3 * gsl[c >> 1] + (c & 1);
+          const double wc0 = Wp[cr * BLD + 2 * g], wc1 = Wp[cr * BLD + 2 * g + 1], lc = lam[cr];
+          for (int i = tid; i < nact; i += T) {
+            const double t = Kb[i * BLD + 2 * g] * wc0 + Kb[i * BLD + 2 * g + 1] * wc1;
+            const double li = lam[i];
+            const double Lic = partial ? (lc + li - li * lc) : 1.0;
+            Wp[i * BLD + c] -= Lic * t;
+          }
+        }
+      }
+      __syncthreads();
+      for (int f = tid; f < len; f += T) {                 // fix_depth (:271) on the state and the running diagonal
+        const int xR = xZ + 5 * f + 4;
+        double rho = xs[xR];
+        const double reset = 1.0 / (2.0 * prm.min_depth);
+        if (rho != rho) { rho = reset; flag |= FLAG_NAN; }
+        if (rho < 0.0) {
+          const double err = reset - rho;
+          diag[f] += err * err;
+          rho = reset;
+          flag |= FLAG_NEGDEPTH;
+        } else if (rho > 1e2) {
+          diag[f] = prm.P0_feat[2];
+          rho = reset;
+        }
+        xs[xR] = rho;
+      }
+      if (res && tid == 0) *res = 0;
+      __syncthreads();
+    }
+    // ---- 3. one pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores.
+    //      D[r][c] = sum_k W[j0+r][k] K[i0+c][k]:  D's column index (lane & 15) runs along the ROWS of P (contiguous in memory).
+    {
+      const int nt = (nact + 15) >> 4;
+      const int lr = lane & 15, lk = lane >> 4;
+      for (int t = wave; t < nt * nt; t += NWV) {
+        const int ti = t % nt, tj = t / nt;
+        const int i0 = 16 * ti, j0t = 16 * tj;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < (2 * BG) / 4; sk++) {
+          const double av = Wp[(j0t + lr) * BLD + 4 * sk + lk];
+          const double bv = Kb[(i0 + lr) * BLD + 4 * sk + lk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        const int i = i0 + lr;
+        if (i < nact) {
+          const double li = lam[i];
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int j = j0t + lk + 4 * rg;
+            if (j < nact) {
+              const double lj = lam[j];
+              const double Lij = partial ? (lj + li - li * lj) : 1.0;
+              double pv = P[i + (long)j * ld] - Lij * acc[rg];
+              if (i == j && i >= 16 && (i - 16) % 3 == 2) pv = diag[(i - 16) / 3];
+              P[i + (long)j * ld] = pv;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < xZ + 5 * len; i += T) {
+    const double v = xs[i];
+    if (v != v) flag |= FLAG_NAN;
+    if (v > 1e6) flag |= FLAG_BLOWUP;
+    xg[i] = v;
+  }
+  if (flag) atomicOr(&a.flags[b], flag);
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic measurement update: VIEKF::update for every measurement model of the reference's table
 // (vi_ekf_meas.cpp:196-278 with h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, :281-386).
 // Each H has at most 6 non-zero columns, so W = P H^T is a combination of <= 6 columns of P and the update is the same
