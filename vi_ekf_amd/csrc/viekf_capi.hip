@@ -120,10 +120,19 @@ size_t lds_propagate(const viekf_batch* b) {
 }
 size_t lds_update(const viekf_batch* b) { return sizeof(double) * (size_t)(b->nxs + 5 * b->n + 32); }
 
+bool stream_mfma_ok() {   // VIEKF_STREAM_BLOCKED=0 keeps the kernels without matrix-core passes (experiments)
+  static const bool ok = []() { const char* e = getenv("VIEKF_STREAM_BLOCKED"); return !(e && atoi(e) == 0); }();
+  return ok;
+}
+
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
   StreamArgs a = make_args(b);
-  hipLaunchKernelGGL(k_propagate_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
-                     d_dt);
+  if (stream_mfma_ok())   // feature/feature part on the fp64 matrix cores
+    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * 9 * (size_t)b->N,
+                       b->stream, a, d_u, d_dt);
+  else
+    hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
+                       d_dt);
   HIP_TRY(hipGetLastError());
   return VIEKF_OK;
 }
@@ -136,10 +145,10 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
   // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass);
   // VIEKF_STREAM_BLOCKED=0 keeps the one-pass-per-measurement kernel (experiments)
-  static const bool blocked_ok = []() { const char* e = getenv("VIEKF_STREAM_BLOCKED"); return !(e && atoi(e) == 0); }();
+  const bool blocked_ok = stream_mfma_ok();
   const BlkLds BL(b->N, b->n, b->nxs);
   const size_t blds = sizeof(double) * (size_t)BL.total;
-  if (blocked_ok && M >= 2 && blds + 1024 <= 160 * 1024) {   // (+ the kernel's small static LDS)
+  if (blocked_ok && M >= 2 && b->n <= 512 && blds + 1024 <= 160 * 1024) {   // (+ the kernel's small static LDS)
     static size_t attr_bytes = 0;
     if (blds > attr_bytes) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_feat_blocked<512>),

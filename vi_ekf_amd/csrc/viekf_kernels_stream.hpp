@@ -29,9 +29,12 @@ struct StreamArgs {
   double* P_out;        // slot of the history ring (viekf_batch_propagate_to: the propagate writes the NEXT slot, no copy)
 };
 
+constexpr int WK = 40;   // contraction depth of the low-rank part (16 + 16 + 6, padded to whole MFMA k-steps of 4)
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 // workspace carve-up (doubles) for one filter
 struct WsLayout {
-  long phi_fb, phi_ff, gd, U, Ut, pbr, pbc, total;
+  long phi_fb, phi_ff, gd, U, Ut, pbr, pbc, Xw, Yw, total;
   __host__ __device__ WsLayout(int N, int n) {
     long o = 0;
     phi_fb = o; o += 3L * N * 16;   // [3N][16]
@@ -41,6 +44,9 @@ struct WsLayout {
     Ut = o;     o += 16L * 3 * N;   // [16][3N]   (P Phi^T)[body rows, feat cols]
     pbr = o;    o += 16L * n;       // [16][n]    copy of P[body rows, :]
     pbc = o;    o += 16L * n;       // [16][n]    copy of P[:, body cols], stored [k][i]
+    const long nfp = ((3L * N + 47) / 48) * 48;
+    Xw = o;     o += nfp * WK;      // [nfp][WK]  low-rank factors of the propagate's MFMA pass (k_propagate_stream<.., true>):
+    Yw = o;     o += nfp * WK;      //            P+_ff = D P_ff D^T + Xw Yw^T, rows padded to whole 48-row super-tiles
     total = (o + 1) & ~1L;
   }
 };
@@ -68,7 +74,8 @@ __device__ __forceinline__ void fix_depth_one(double* xs, double* P, int ld, int
 // ------------------------------------------------------------------------------------------------
 // propagate: numeric core of VIEKF::propagate_state (vi_ekf.cpp:262-318)
 // ------------------------------------------------------------------------------------------------
-template <int T>
+// MF = true: the feature/feature part runs on the fp64 matrix cores (see the pass at the end); otherwise one 3x3 block per thread.
+template <int T, bool MF>
 __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const double* __restrict__ u_all,
                                                         const double* __restrict__ dt_all) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -85,6 +92,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   double* T16 = Pbb + 256;              // 16x16 scratch
   double* xdb = T16 + 256;              // 16
   BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
+  double* Dl = xdb + 16 + (sizeof(BodyCtx) + 7) / 8;   // [N][9] Phi_ff blocks (MF only)
 
   double* xg = a.x + (long)b * a.nxs;
   double* P = a.P + (long)b * n * ld;
@@ -144,7 +152,9 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     for (int e = 0; e < 9; e++) {
       const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
       Mff[e] = id + Aff[e] * dt / 2.0 + Aff2[e] * dt * dt / 6.0;
-      phi_ff[9 * i + e] = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
+      const double ph = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
+      phi_ff[9 * i + e] = ph;
+      if (MF) Dl[9 * i + e] = ph;
     }
     double gacc[18];
     for (int e = 0; e < 18; e++) gacc[e] = 0.0;
@@ -205,13 +215,28 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
       s += ph * Pbb[c * 16 + k];
       st += Pbb[k * 16 + c] * ph;
     }
+    double vt = 0.0;
     for (int m = 0; m < 3; m++) {
       const double pf = phi_ff[9 * I + rr * 3 + m];
       s += pf * pbc[k * n + 16 + 3 * I + m];
-      st += pbr[k * n + 16 + 3 * I + m] * pf;
+      vt += pbr[k * n + 16 + 3 * I + m] * pf;
     }
+    st += vt;
     U[r * 16 + k] = s;
     Ut[k * nf + r] = st;
+    if (MF) {
+      // rows of the low-rank factors:  P+_ff - D P_ff D^T = U Phi_fb^T + Phi_fb (P_bf D^T) + (Gd Qu) Gd^T = Xw Yw^T
+      double* xr = ws + L.Xw + (long)r * WK;
+      double* yr = ws + L.Yw + (long)r * WK;
+      const double ph = phi_fb[r * 16 + k];
+      xr[k] = s;       yr[k] = ph;
+      xr[16 + k] = ph; yr[16 + k] = vt;
+      if (k < 8) {
+        const double g = (k < 6) ? gd[(16 + r) * 6 + k] : 0.0;
+        xr[32 + k] = (k < 6) ? g * a.dp->Qu[k] : 0.0;
+        yr[32 + k] = g;
+      }
+    }
   }
   for (int e = tid; e < 256; e += T) {
     const int r = e >> 4, c = e & 15;
@@ -245,33 +270,123 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     P[(16 + r) + (long)k * ld] = s + g;
     P[k + (long)(16 + r) * ld] = st + g;
   }
-  // ---- feature/feature 3x3 blocks, in place (each block needs only itself + saved body strips)
-  for (int e = tid; e < len * len; e += T) {
-    const int I = e % len, J = e / len;
-    const int r0 = 16 + 3 * I, c0 = 16 + 3 * J;
-    double Pij[9], Mij[9], out[9];
-    for (int c = 0; c < 3; c++)
-      for (int r = 0; r < 3; r++) Pij[r * 3 + c] = P[(r0 + r) + (long)(c0 + c) * ld];
-    for (int r = 0; r < 3; r++)
-      for (int m = 0; m < 3; m++) {
-        double s = 0.0;
-        for (int k = 0; k < 16; k++) s += phi_fb[(3 * I + r) * 16 + k] * pbr[k * n + c0 + m];
-        for (int q = 0; q < 3; q++) s += phi_ff[9 * I + r * 3 + q] * Pij[q * 3 + m];
-        Mij[r * 3 + m] = s;
+  if constexpr (MF) {
+    // ---- feature/feature part on the matrix cores.  With D = blockdiag(Phi_ff) the new block is
+    //        P+_ff = D P_ff D^T + Xw Yw^T          (Xw, Yw: nf x 38, rows written above)
+    //      One wave per 48 x 48 super-tile (16 features square, so D never straddles a tile), v_mfma_f64_16x16x4_f64:
+    //        R   = P_IJ D_J^T              A = P (lane & 15 along the rows of P: coalesced loads), B = D_J^T built from LDS
+    //        O^T = R^T D_I^T               A = R straight from the accumulators: register s of a 16x16 result IS the operand of
+    //                                      k-step s (row (lane>>4) + 4 s), so the chain needs no data movement
+    //        O^T += Yw_J Xw_I^T            10 k-steps
+    //      O^T has lane & 15 along the rows of P again: coalesced stores.  D is block-diagonal, so only the k-steps that
+    //      overlap a tile's features are issued (16 of 36 per product).  In place: a super-tile depends on itself only.
+    __syncthreads();   // Xw / Yw rows and Dl are complete (this block's global writes are visible to it after the barrier)
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    constexpr int NWV = T / 64;
+    const int nst = (nf + 47) / 48;
+    const double* Xw = ws + L.Xw;
+    const double* Yw = ws + L.Yw;
+    // operand element D[16 q + lr][4 s + lk] of the 48 x 48 block-diagonal matrix of super-tile `sup`
+    auto dop = [&](int sup, int q, int s) -> double {
+      const int jp = 16 * q + lr, j = 4 * s + lk;
+      const int fp = jp / 3, f = j / 3, F = 16 * sup + fp;
+      return (fp == f && F < len) ? Dl[9 * F + (jp - 3 * fp) * 3 + (j - 3 * f)] : 0.0;
+    };
+    for (int st = wave; st < nst * nst; st += NWV) {
+      const int I = st % nst, J = st / nst;
+      const int r0 = 16 + 48 * I, c0 = 16 + 48 * J;
+      double pA[3][12];
+#pragma unroll
+      for (int aa = 0; aa < 3; aa++)
+#pragma unroll
+        for (int s = 0; s < 12; s++)
+          pA[aa][s] = P[min(r0 + 16 * aa + lr, nact - 1) + (long)min(c0 + 4 * s + lk, nact - 1) * ld];
+      v4f64 R[3][3], O[3][3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int aa = 0; aa < 3; aa++) { R[aa][q] = v4f64{0.0, 0.0, 0.0, 0.0}; O[q][aa] = v4f64{0.0, 0.0, 0.0, 0.0}; }
       }
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) {
-        double s = 0.0;
-        for (int k = 0; k < 16; k++) s += U[(3 * I + r) * 16 + k] * phi_fb[(3 * J + c) * 16 + k];
-        for (int m = 0; m < 3; m++) s += Mij[r * 3 + m] * phi_ff[9 * J + c * 3 + m];
-        double g = 0.0;
-        for (int q = 0; q < 6; q++) g += gd[(r0 + r) * 6 + q] * a.dp->Qu[q] * gd[(c0 + c) * 6 + q];
-        s = s + g;
-        if (I == J && r == c) s += a.Qx[r0 + r];
-        out[r * 3 + c] = s;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        constexpr int S0[3] = {0, 3, 7}, S1[3] = {4, 8, 11};   // k-steps (4 columns each) that touch the features of tile q
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+          if (s < S0[q] || s > S1[q]) continue;
+          const double bd = dop(J, q, s);
+#pragma unroll
+          for (int aa = 0; aa < 3; aa++) R[aa][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[aa][s], bd, R[aa][q], 0, 0, 0);
+        }
       }
-    for (int c = 0; c < 3; c++)
-      for (int r = 0; r < 3; r++) P[(r0 + r) + (long)(c0 + c) * ld] = out[r * 3 + c];
+#pragma unroll
+      for (int aa = 0; aa < 3; aa++) {
+        constexpr int S0[3] = {0, 3, 7}, S1[3] = {4, 8, 11};
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+          if (s < S0[aa] || s > S1[aa]) continue;
+          const double bi = dop(I, aa, s);
+#pragma unroll
+          for (int q = 0; q < 3; q++) O[q][aa] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[s / 4][q][s % 4], bi, O[q][aa], 0, 0, 0);
+        }
+      }
+#pragma unroll 2
+      for (int s = 0; s < WK / 4; s++) {
+        double yv[3], xv[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          yv[q] = Yw[(long)(48 * J + 16 * q + lr) * WK + 4 * s + lk];
+          xv[q] = Xw[(long)(48 * I + 16 * q + lr) * WK + 4 * s + lk];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+          for (int aa = 0; aa < 3; aa++) O[q][aa] = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[q], xv[aa], O[q][aa], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int aa = 0; aa < 3; aa++) {
+          const int i = r0 + 16 * aa + lr;
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int j = c0 + 16 * q + lk + 4 * rg;
+            if (i < nact && j < nact) {
+              double v = O[q][aa][rg];
+              if (i == j) v += a.Qx[i];
+              P[i + (long)j * ld] = v;
+            }
+          }
+        }
+    }
+  } else {
+    // ---- feature/feature 3x3 blocks, in place (each block needs only itself + saved body strips)
+    for (int e = tid; e < len * len; e += T) {
+      const int I = e % len, J = e / len;
+      const int r0 = 16 + 3 * I, c0 = 16 + 3 * J;
+      double Pij[9], Mij[9], out[9];
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) Pij[r * 3 + c] = P[(r0 + r) + (long)(c0 + c) * ld];
+      for (int r = 0; r < 3; r++)
+        for (int m = 0; m < 3; m++) {
+          double s = 0.0;
+          for (int k = 0; k < 16; k++) s += phi_fb[(3 * I + r) * 16 + k] * pbr[k * n + c0 + m];
+          for (int q = 0; q < 3; q++) s += phi_ff[9 * I + r * 3 + q] * Pij[q * 3 + m];
+          Mij[r * 3 + m] = s;
+        }
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+          double s = 0.0;
+          for (int k = 0; k < 16; k++) s += U[(3 * I + r) * 16 + k] * phi_fb[(3 * J + c) * 16 + k];
+          for (int m = 0; m < 3; m++) s += Mij[r * 3 + m] * phi_ff[9 * J + c * 3 + m];
+          double g = 0.0;
+          for (int q = 0; q < 6; q++) g += gd[(r0 + r) * 6 + q] * a.dp->Qu[q] * gd[(c0 + c) * 6 + q];
+          s = s + g;
+          if (I == J && r == c) s += a.Qx[r0 + r];
+          out[r * 3 + c] = s;
+        }
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) P[(r0 + r) + (long)(c0 + c) * ld] = out[r * 3 + c];
+    }
   }
   // inactive slots: Phi = I and G = 0 there, so only Qx is added (vi_ekf.cpp:139-144,304)
   for (int d = nact + tid; d < n; d += T) P[d + (long)d * ld] += a.Qx[d];
@@ -423,27 +538,30 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
 // M sequential active FEAT updates, BLOCKED for a covariance that does not fit on chip (wide P): the same arithmetic
 // as k_update_feat_stream, but P crosses HBM once per GROUP of up to BG measurements instead of once per measurement.
 //   1. panel:  the 2 zeta columns of every feature measured in the group, all rows, -> LDS  (n x 2 BG)
-//   2. for each measurement of the group, in order: innovation, gate, W = panel_g Hb^T (in place), K = W S^-1, state
-//      correction, fix_depth; the rank-2 update is applied to the LATER panel columns only (they are all that the
-//      following gains need) and to an exact running copy of the rho-rho diagonal (fix_depth edits it, vi_ekf_helper.cpp:
-//      128-156, and a "set" does not commute with later updates).
-//   3. one pass over P:  P -= Lambda o (K W^T)  with K, W = n x 2 BG from LDS -- a dense contraction, done per 16x16 tile by
-//      v_mfma_f64_16x16x4_f64 (4 k-steps), Lambda applied to the accumulator; the rho-rho diagonal takes the running copy.
-// A slot that repeats inside a group starts a new group.  HBM traffic per step drops from (M+1) to (M/BG+1) passes over P.
-// LDS rows of K / W are 18 doubles apart: the MFMA operand reads (16 consecutive rows per k) then hit distinct banks.
+//   2. for each measurement of the group, in order: innovation, gate, W = panel_g Hb^T (in place), K = W S^-1 (in
+//      registers; only S^-1 is kept), state correction, fix_depth; the rank-2 update is applied to the LATER panel columns
+//      only (they are all that the following gains need) and to an exact running copy of the rho-rho diagonal (fix_depth
+//      edits it, vi_ekf_helper.cpp:128-156, and a "set" does not commute with later updates).
+//   3. one pass over P:  P -= Lambda o (K W^T)  with W = n x 2 BG from LDS and K = W S^-1 re-formed on the fly -- a dense
+//      contraction, done per 16x16 tile by v_mfma_f64_16x16x4_f64 (BG/2 k-steps), Lambda applied to the accumulator; the
+//      rho-rho diagonal takes the running copy.
+// A slot that repeats inside a group starts a new group.  HBM traffic per step drops from (M+1) to (M/BG+1) passes over P;
+// keeping W alone (K costs two multiply-adds per operand instead of 127 KB of LDS) is what lets BG = 16 fit at N = 160.
+// LDS rows of W are 34 doubles apart: the MFMA operand reads (16 consecutive rows per k) then spread over the banks.
 // ------------------------------------------------------------------------------------------------
-constexpr int BG = 8;     // measurements per group
-constexpr int BLD = 18;   // LDS row stride (doubles) of the n x 16 gain arrays
-typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int BG = 16;    // measurements per group
+constexpr int BLD = 34;   // LDS row stride (doubles) of the n x 32 panel
+constexpr int BWIN = 32;  // measurement-list entries staged per group
 
 struct BlkLds {
-  int xs, lam, Wp, Kb, sm, diag, gsl, total;   // offsets in doubles
+  int xs, lam, Wp, Si, sm, diag, gsl, win, total;   // offsets in doubles
   __host__ __device__ BlkLds(int N, int n, int nxs) {
     const int nr = (n + 15) & ~15;
     int o = 0;
     auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
-    xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Kb = take(nr * BLD); sm = take(32); diag = take(N > 0 ? N : 1);
+    xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Si = take(4 * BG); sm = take(32); diag = take(N > 0 ? N : 1);
     gsl = take(2 * BG);   // ints: slot[BG], measurement index[BG]
+    win = take(7 * BWIN);   // staged window of the measurement list: z [BWIN][2], R [BWIN][4], slot [BWIN] (ints)
     total = o;
   }
 };
@@ -461,11 +579,14 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   double* xs = smem + L.xs;
   double* lam = smem + L.lam;
   double* Wp = smem + L.Wp;     // panel of raw columns, turned into W pair by pair
-  double* Kb = smem + L.Kb;
+  double* SiL = smem + L.Si;    // per pair g: {Si00, Si10, Si01, Si11} = the two COLUMNS of S^-1 (zero if the update was skipped)
   double* sm = smem + L.sm;
   double* diag = smem + L.diag; // running P(rho_f, rho_f)
   int* gsl = reinterpret_cast<int*>(smem + L.gsl);
   int* gml = gsl + BG;
+  double* wz = smem + L.win;
+  double* wR = wz + 2 * BWIN;
+  int* wsl = reinterpret_cast<int*>(wR + 4 * BWIN);
   double* xg = a.x + (long)b * a.nxs;
   double* P = a.P + (long)b * n * ld;
   const int len = a.len[b];
@@ -474,67 +595,85 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   const bool partial = prm.use_partial_update != 0;
   unsigned flag = 0;
   constexpr int NWV = T / 64;
+  constexpr int RPT = 1;        // rows per thread in the panel phase (T * RPT >= n: checked on the host)
   const int lane = tid & 63, wave = tid >> 6;
 
   for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
   for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
   __syncthreads();
 
-  int m = 0;
+  int m = 0, mbase = 0;
   while (m < M) {
-    // ---- form the next group (every thread scans the same list: uniform control flow; tid 0 records it)
+    // ---- stage a window of the measurement list in LDS (one parallel fetch instead of a chain of dependent global loads),
+    //      then form the next group from it (every thread scans the same list: uniform control flow; tid 0 records it)
+    __syncthreads();   // (the previous group is done with the window)
+    if (tid < BWIN && m + tid < M) {
+      const long mi = (long)b * M + m + tid;
+      const int slot = slot_all[mi];
+      const double z0 = z_all[2 * mi], z1 = z_all[2 * mi + 1];
+      int code = 0;
+      if (slot < 0) code = -1;
+      else if (slot >= len) code = 3;                   // MEAS_INVALID
+      else if (z0 != z0 || z1 != z1) code = 2;          // MEAS_NAN (vi_ekf_meas.cpp:136-137)
+      wsl[tid] = code == 0 ? slot : -1;
+      wz[2 * tid] = z0; wz[2 * tid + 1] = z1;
+      const double* R = R_all + (long)b * r_stride_b + (long)(m + tid) * r_stride_m;   // column-major 2x2
+      wR[4 * tid] = R[0]; wR[4 * tid + 1] = R[1]; wR[4 * tid + 2] = R[2]; wR[4 * tid + 3] = R[3];
+      if (code != 0 && result_all) result_all[mi] = code;
+    }
+    __syncthreads();
     int Gn = 0;
     {
       int mm = m;
-      unsigned long long seen_lo = 0, seen_hi = 0;   // slots already in the group (N <= 128 covers the 160-feature limit? no: 3 words)
-      unsigned long long seen_h2 = 0;
-      while (mm < M && Gn < BG) {
-        const int slot = slot_all[(long)b * M + mm];
-        const double z0 = z_all[((long)b * M + mm) * 2], z1 = z_all[((long)b * M + mm) * 2 + 1];
-        int code = 0;
-        if (slot < 0) code = -1;
-        else if (slot >= len) code = 3;                 // MEAS_INVALID
-        else if (z0 != z0 || z1 != z1) code = 2;        // MEAS_NAN (vi_ekf_meas.cpp:136-137)
-        if (code != 0) {
-          if (result_all && tid == 0) result_all[(long)b * M + mm] = code;
-          mm++;
-          continue;
+      const int mend = min(M, m + BWIN);
+      unsigned long long seen0 = 0, seen1 = 0, seen2 = 0;   // slots already in the group (3 x 64 >= the 160-feature limit)
+      while (mm < mend && Gn < BG) {
+        const int slot = wsl[mm - m];
+        if (slot >= 0) {
+          unsigned long long& w = slot < 64 ? seen0 : (slot < 128 ? seen1 : seen2);
+          const unsigned long long bit = 1ull << (slot & 63);
+          if (w & bit) break;                             // repeated slot: it opens the next group
+          w |= bit;
+          if (tid == 0) { gsl[Gn] = slot; gml[Gn] = mm - m; }   // (index into the window)
+          Gn++;
         }
-        unsigned long long& w = slot < 64 ? seen_lo : (slot < 128 ? seen_hi : seen_h2);
-        const unsigned long long bit = 1ull << (slot & 63);
-        if (w & bit) break;                             // repeated slot: it opens the next group
-        w |= bit;
-        if (tid == 0) { gsl[Gn] = slot; gml[Gn] = mm; }
-        Gn++;
         mm++;
       }
+      const int m0 = m;
       m = mm;
+      mbase = m0;
     }
     if (Gn == 0) continue;
     __syncthreads();
     // ---- 1. panel <- the zeta columns of the group's features (coalesced along the rows); unused columns <- 0
-    for (int c = 0; c < 2 * BG; c++) {
-      if (c < 2 * Gn) {
-        const int col = 16 + 3 * gsl[c >> 1] + (c & 1);
-        for (int i = tid; i < nact; i += T) Wp[i * BLD + c] = P[i + (long)col * ld];
-      } else {
-        for (int i = tid; i < nact; i += T) { Wp[i * BLD + c] = 0.0; Kb[i * BLD + c] = 0.0; }
+    for (int i = tid; i < nact; i += T) {
+#pragma unroll 1
+      for (int c0 = 0; c0 < 2 * BG; c0 += 8) {           // eight independent column loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int c = c0 + k;
+          v[k] = (c < 2 * Gn) ? P[i + (long)(16 + 3 * gsl[c >> 1] + (c & 1)) * ld] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(Wp + i * BLD + c0 + k) = make_double2(v[k], v[k + 1]);
       }
     }
+    if (tid < 4 * BG) SiL[tid] = 0.0;
     for (int f = tid; f < len; f += T) diag[f] = P[(16 + 3 * f + 2) + (long)(16 + 3 * f + 2) * ld];
     __syncthreads();
     // ---- 2. the measurements of the group, in order
     for (int g = 0; g < Gn; g++) {
-      const int slot = gsl[g], mi = gml[g];
-      int* res = result_all ? &result_all[(long)b * M + mi] : nullptr;
-      const double* R = R_all + (long)b * r_stride_b + (long)mi * r_stride_m;   // column-major 2x2
+      const int slot = gsl[g], wi = gml[g];
+      int* res = result_all ? &result_all[(long)b * M + mbase + wi] : nullptr;
+      const double* R = wR + 4 * wi;                                // column-major 2x2
       const int j0 = 16 + 3 * slot;
       if (tid == 0) {
         double zhat[2], Hb[4];
         h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
         sm[2] = Hb[0]; sm[3] = Hb[1]; sm[4] = Hb[2]; sm[5] = Hb[3];
-        sm[6] = z_all[((long)b * M + mi) * 2] - zhat[0];           // residual (vi_ekf_meas.cpp:220)
-        sm[7] = z_all[((long)b * M + mi) * 2 + 1] - zhat[1];
+        sm[6] = wz[2 * wi] - zhat[0];                               // residual (vi_ekf_meas.cpp:220)
+        sm[7] = wz[2 * wi + 1] - zhat[1];
       }
       __syncthreads();
       const double h00 = sm[2], h01 = sm[3], h10 = sm[4], h11 = sm[5], r0 = sm[6], r1 = sm[7];
@@ -554,44 +693,56 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       __syncthreads();   // (everyone has read P_zz before the rows below overwrite the pair with W)
       if (mahal > 9.0) {                                   // gate (:235-239): returns before fix_depth
         if (res && tid == 0) *res = 1;
-        for (int i = tid; i < nact; i += T) {
-          Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; Kb[i * BLD + 2 * g] = 0.0; Kb[i * BLD + 2 * g + 1] = 0.0;
-        }
+        for (int i = tid; i < nact; i += T) { Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; }
         __syncthreads();
         continue;
       }
       int bad = 0;
-      for (int i = tid; i < nact; i += T) {                // W = P H^T, K = W S^-1 (:241), NaN guard (:247)
-        const double p0 = Wp[i * BLD + 2 * g], p1 = Wp[i * BLD + 2 * g + 1];
-        const double w0 = p0 * h00 + p1 * h01, w1 = p0 * h10 + p1 * h11;
-        const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
-        Wp[i * BLD + 2 * g] = w0; Wp[i * BLD + 2 * g + 1] = w1;
-        Kb[i * BLD + 2 * g] = k0; Kb[i * BLD + 2 * g + 1] = k1;
-        if (k0 != k0 || k1 != k1) bad = 1;
+      double kr[RPT][2];                                   // this thread's rows of K (rows tid, tid + T)
+#pragma unroll
+      for (int u = 0; u < RPT; u++) {                      // W = P H^T, K = W S^-1 (:241), NaN guard (:247)
+        const int i = tid + u * T;
+        kr[u][0] = 0.0; kr[u][1] = 0.0;
+        if (i < nact) {
+          const double p0 = Wp[i * BLD + 2 * g], p1 = Wp[i * BLD + 2 * g + 1];
+          const double w0 = p0 * h00 + p1 * h01, w1 = p0 * h10 + p1 * h11;
+          const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
+          Wp[i * BLD + 2 * g] = w0; Wp[i * BLD + 2 * g + 1] = w1;
+          kr[u][0] = k0; kr[u][1] = k1;
+          if (k0 != k0 || k1 != k1) bad = 1;
+        }
       }
       if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
       bad = __syncthreads_or(bad);
       if (bad) {
-        for (int i = tid; i < nact; i += T) {
-          Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; Kb[i * BLD + 2 * g] = 0.0; Kb[i * BLD + 2 * g + 1] = 0.0;
-        }
+        for (int i = tid; i < nact; i += T) { Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; }
       } else {
-        // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263)
+        if (tid == 0) { SiL[4 * g + 0] = Si[0]; SiL[4 * g + 1] = Si[2]; SiL[4 * g + 2] = Si[1]; SiL[4 * g + 3] = Si[3]; }
+        // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263);  K rows re-formed from W where needed
+        auto krow = [&](int i, double& k0, double& k1) {
+          const double w0 = Wp[i * BLD + 2 * g], w1 = Wp[i * BLD + 2 * g + 1];
+          k0 = w0 * Si[0] + w1 * Si[2]; k1 = w0 * Si[1] + w1 * Si[3];
+        };
         if (tid == 0) {
           double dxb[16], xo[17];
           for (int i = 0; i < 16; i++) {
             const double l = partial ? lam[i] : 1.0;
-            dxb[i] = (l * Kb[i * BLD + 2 * g]) * r0 + (l * Kb[i * BLD + 2 * g + 1]) * r1;
+            double k0, k1;
+            krow(i, k0, k1);
+            dxb[i] = (l * k0) * r0 + (l * k1) * r1;
           }
           body_boxplus(xs, dxb, xo);
           for (int i = 0; i < 17; i++) xs[i] = xo[i];
         }
         for (int f = tid; f < len; f += T) {
           const int d = 16 + 3 * f;
-          double dv[3];
+          double dv[3], k2[2] = {0.0, 0.0};
           for (int q = 0; q < 3; q++) {
             const double l = partial ? lam[d + q] : 1.0;
-            dv[q] = (l * Kb[(d + q) * BLD + 2 * g]) * r0 + (l * Kb[(d + q) * BLD + 2 * g + 1]) * r1;
+            double k0, k1;
+            krow(d + q, k0, k1);
+            dv[q] = (l * k0) * r0 + (l * k1) * r1;
+            k2[0] = k0; k2[1] = k1;
           }
           double qn[4];
           q_feat_boxplus(xs + xZ + 5 * f, dv[0], dv[1], qn);
@@ -602,17 +753,21 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
           const int ir = d + 2;
           const double li = lam[ir];
           const double Lii = partial ? (li + li - li * li) : 1.0;
-          diag[f] -= Lii * (Kb[ir * BLD + 2 * g] * Wp[ir * BLD + 2 * g] + Kb[ir * BLD + 2 * g + 1] * Wp[ir * BLD + 2 * g + 1]);
+          diag[f] -= Lii * (k2[0] * Wp[ir * BLD + 2 * g] + k2[1] * Wp[ir * BLD + 2 * g + 1]);
         }
         // the later panel columns follow the update:  P_ic -= Lambda_ic (K_i . W_c)
         for (int c = 2 * (g + 1); c < 2 * Gn; c++) {
           const int cr = 16 + 3 * gsl[c >> 1] + (c & 1);
           const double wc0 = Wp[cr * BLD + 2 * g], wc1 = Wp[cr * BLD + 2 * g + 1], lc = lam[cr];
-          for (int i = tid; i < nact; i += T) {
-            const double t = Kb[i * BLD + 2 * g] * wc0 + Kb[i * BLD + 2 * g + 1] * wc1;
-            const double li = lam[i];
-            const double Lic = partial ? (lc + li - li * lc) : 1.0;
-            Wp[i * BLD + c] -= Lic * t;
+#pragma unroll
+          for (int u = 0; u < RPT; u++) {
+            const int i = tid + u * T;
+            if (i < nact) {
+              const double t = kr[u][0] * wc0 + kr[u][1] * wc1;
+              const double li = lam[i];
+              const double Lic = partial ? (lc + li - li * lc) : 1.0;
+              Wp[i * BLD + c] -= Lic * t;
+            }
           }
         }
       }
@@ -641,31 +796,68 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
     {
       const int nt = (nact + 15) >> 4;
       const int lr = lane & 15, lk = lane >> 4;
-      for (int t = wave; t < nt * nt; t += NWV) {
-        const int ti = t % nt, tj = t / nt;
-        const int i0 = 16 * ti, j0t = 16 * tj;
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
+      constexpr int TPI = 4;   // tiles per wave and iteration: their 16 loads of P are in flight together (one tile at a time
+                               // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
+      auto load_tiles = [&](int tb, double (&pq)[TPI][4]) {
 #pragma unroll
-        for (int sk = 0; sk < (2 * BG) / 4; sk++) {
-          const double av = Wp[(j0t + lr) * BLD + 4 * sk + lk];
-          const double bv = Kb[(i0 + lr) * BLD + 4 * sk + lk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-        const int i = i0 + lr;
-        if (i < nact) {
-          const double li = lam[i];
+        for (int q = 0; q < TPI; q++) {
+          const int t = min(tb + q * NWV, nt * nt - 1);   // (clamped, unconditional loads: branch-free, so the compiler can
+          const int ti = t % nt, tj = t / nt;             //  count them exactly instead of draining the queue at every use)
+          const int i = min(16 * ti + lr, nact - 1);
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
-            const int j = j0t + lk + 4 * rg;
-            if (j < nact) {
-              const double lj = lam[j];
-              const double Lij = partial ? (lj + li - li * lj) : 1.0;
-              double pv = P[i + (long)j * ld] - Lij * acc[rg];
-              if (i == j && i >= 16 && (i - 16) % 3 == 2) pv = diag[(i - 16) / 3];
-              P[i + (long)j * ld] = pv;
-            }
+            const int j = min(16 * tj + lk + 4 * rg, nact - 1);
+            pq[q][rg] = P[i + (long)j * ld];
           }
         }
+      };
+      double pv[TPI][4], pn[TPI][4];
+      load_tiles(wave, pv);
+      for (int tb = wave; tb < nt * nt; tb += NWV * TPI) {
+        load_tiles(tb + NWV * TPI, pn);   // the next iteration's tiles are on the wire during this one's contraction
+#pragma unroll
+        for (int q = 0; q < TPI; q++) {
+          const int t = tb + q * NWV;
+          if (t >= nt * nt) break;
+          const int ti = t % nt, tj = t / nt;
+          const int i0 = 16 * ti, j0t = 16 * tj;
+          v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+          for (int sk = 0; sk < ksteps; sk++) {
+            const int c = 4 * sk + lk;                       // this lane's contraction index: column c of pair c >> 1
+            const double av = Wp[(j0t + lr) * BLD + c];
+            const double2 wv = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
+            const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+            const double bv = wv.x * sv.x + wv.y * sv.y;    // K[i][c], the same expression as in the panel phase
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+          const int i = i0 + lr;
+          const double li = lam[min(i, nact - 1)];
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {                   // (results stay in pv: every store is issued after the last
+            const int j = j0t + lk + 4 * rg;                 //  wait on a load -- a store ahead of a load wait would be waited for too)
+            const double lj = lam[min(j, nact - 1)];
+            const double Lij = partial ? (lj + li - li * lj) : 1.0;
+            double v = pv[q][rg] - Lij * acc[rg];
+            if (i == j && i >= 16 && i < nact && (i - 16) % 3 == 2) v = diag[(i - 16) / 3];
+            pv[q][rg] = v;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < TPI; q++) {
+          const int t = tb + q * NWV;
+          const int ti = t % nt, tj = t / nt;
+          const int i = 16 * ti + lr;
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int j = 16 * tj + lk + 4 * rg;
+            if (t < nt * nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < TPI; q++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) pv[q][rg] = pn[q][rg];
       }
     }
     __syncthreads();
