@@ -11,6 +11,7 @@
 //      P_ij -= Lambda_ij (K_i . W_j),  Lambda_ij = l_i + l_j - l_i l_j  (vi_ekf.cpp:83,146).
 #pragma once
 #include "viekf_device.hpp"
+#include "viekf_fastmath.hpp"
 
 namespace viekf {
 
@@ -559,7 +560,8 @@ struct BlkLds {
     const int nr = (n + 15) & ~15;
     int o = 0;
     auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
-    xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Si = take(4 * BG); sm = take(32); diag = take(N > 0 ? N : 1);
+    xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Si = take(4 * BG); sm = take(32);   // sm: pzz[2][4] (+ spare)
+    diag = take(N > 0 ? N : 1);
     gsl = take(2 * BG);   // ints: slot[BG], measurement index[BG]
     win = take(7 * BWIN);   // staged window of the measurement list: z [BWIN][2], R [BWIN][4], slot [BWIN] (ints)
     total = o;
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   double* lam = smem + L.lam;
   double* Wp = smem + L.Wp;     // panel of raw columns, turned into W pair by pair
   double* SiL = smem + L.Si;    // per pair g: {Si00, Si10, Si01, Si11} = the two COLUMNS of S^-1 (zero if the update was skipped)
-  double* sm = smem + L.sm;
+  double* pzz = smem + L.sm;    // [2][4] zeta-zeta block of the current / next measurement
   double* diag = smem + L.diag; // running P(rho_f, rho_f)
   int* gsl = reinterpret_cast<int*>(smem + L.gsl);
   int* gml = gsl + BG;
@@ -661,118 +663,18 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
     }
     if (tid < 4 * BG) SiL[tid] = 0.0;
     for (int f = tid; f < len; f += T) diag[f] = P[(16 + 3 * f + 2) + (long)(16 + 3 * f + 2) * ld];
-    __syncthreads();
-    // ---- 2. the measurements of the group, in order
-    for (int g = 0; g < Gn; g++) {
-      const int slot = gsl[g], wi = gml[g];
-      int* res = result_all ? &result_all[(long)b * M + mbase + wi] : nullptr;
-      const double* R = wR + 4 * wi;                                // column-major 2x2
-      const int j0 = 16 + 3 * slot;
-      if (tid == 0) {
-        double zhat[2], Hb[4];
-        h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
-        sm[2] = Hb[0]; sm[3] = Hb[1]; sm[4] = Hb[2]; sm[5] = Hb[3];
-        sm[6] = wz[2 * wi] - zhat[0];                               // residual (vi_ekf_meas.cpp:220)
-        sm[7] = wz[2 * wi + 1] - zhat[1];
+    // The zeta-zeta 2x2 of the measurement about to be processed is handed over in pzz[parity][4] by the two threads that own
+    // its rows (they are the ones that keep those panel entries current), so nobody reads panel rows that are being rewritten.
+    const int i = tid;                                      // this thread's row of the panel (T >= n, checked on the host)
+    auto publish_pzz = [&](int gn) {                        // for measurement gn of the group, from the thread's own row
+      if (gn < Gn) {
+        const int jn = 16 + 3 * gsl[gn];
+        if (i == jn || i == jn + 1)
+          *reinterpret_cast<double2*>(pzz + 4 * (gn & 1) + 2 * (i - jn)) = *reinterpret_cast<const double2*>(Wp + i * BLD + 2 * gn);
       }
-      __syncthreads();
-      const double h00 = sm[2], h01 = sm[3], h10 = sm[4], h11 = sm[5], r0 = sm[6], r1 = sm[7];
-      double S[4], Si[4];
-      {   // S = Hb P_zz Hb^T + R from the panel (current columns of this feature), uniform
-        const double p00 = Wp[j0 * BLD + 2 * g], p01 = Wp[j0 * BLD + 2 * g + 1];
-        const double p10 = Wp[(j0 + 1) * BLD + 2 * g], p11 = Wp[(j0 + 1) * BLD + 2 * g + 1];
-        const double w00 = p00 * h00 + p01 * h01, w01 = p00 * h10 + p01 * h11;      // W rows j0, j0+1
-        const double w10 = p10 * h00 + p11 * h01, w11 = p10 * h10 + p11 * h11;
-        S[0] = h00 * w00 + h01 * w10 + R[0];
-        S[1] = h00 * w01 + h01 * w11 + R[2];
-        S[2] = h10 * w00 + h11 * w10 + R[1];
-        S[3] = h10 * w01 + h11 * w11 + R[3];
-      }
-      inv2(S, Si);
-      const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;   // vi_ekf_meas.cpp:234
-      __syncthreads();   // (everyone has read P_zz before the rows below overwrite the pair with W)
-      if (mahal > 9.0) {                                   // gate (:235-239): returns before fix_depth
-        if (res && tid == 0) *res = 1;
-        for (int i = tid; i < nact; i += T) { Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; }
-        __syncthreads();
-        continue;
-      }
-      int bad = 0;
-      double kr[RPT][2];                                   // this thread's rows of K (rows tid, tid + T)
-#pragma unroll
-      for (int u = 0; u < RPT; u++) {                      // W = P H^T, K = W S^-1 (:241), NaN guard (:247)
-        const int i = tid + u * T;
-        kr[u][0] = 0.0; kr[u][1] = 0.0;
-        if (i < nact) {
-          const double p0 = Wp[i * BLD + 2 * g], p1 = Wp[i * BLD + 2 * g + 1];
-          const double w0 = p0 * h00 + p1 * h01, w1 = p0 * h10 + p1 * h11;
-          const double k0 = w0 * Si[0] + w1 * Si[2], k1 = w0 * Si[1] + w1 * Si[3];
-          Wp[i * BLD + 2 * g] = w0; Wp[i * BLD + 2 * g + 1] = w1;
-          kr[u][0] = k0; kr[u][1] = k1;
-          if (k0 != k0 || k1 != k1) bad = 1;
-        }
-      }
-      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
-      bad = __syncthreads_or(bad);
-      if (bad) {
-        for (int i = tid; i < nact; i += T) { Wp[i * BLD + 2 * g] = 0.0; Wp[i * BLD + 2 * g + 1] = 0.0; }
-      } else {
-        if (tid == 0) { SiL[4 * g + 0] = Si[0]; SiL[4 * g + 1] = Si[2]; SiL[4 * g + 2] = Si[1]; SiL[4 * g + 3] = Si[3]; }
-        // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263);  K rows re-formed from W where needed
-        auto krow = [&](int i, double& k0, double& k1) {
-          const double w0 = Wp[i * BLD + 2 * g], w1 = Wp[i * BLD + 2 * g + 1];
-          k0 = w0 * Si[0] + w1 * Si[2]; k1 = w0 * Si[1] + w1 * Si[3];
-        };
-        if (tid == 0) {
-          double dxb[16], xo[17];
-          for (int i = 0; i < 16; i++) {
-            const double l = partial ? lam[i] : 1.0;
-            double k0, k1;
-            krow(i, k0, k1);
-            dxb[i] = (l * k0) * r0 + (l * k1) * r1;
-          }
-          body_boxplus(xs, dxb, xo);
-          for (int i = 0; i < 17; i++) xs[i] = xo[i];
-        }
-        for (int f = tid; f < len; f += T) {
-          const int d = 16 + 3 * f;
-          double dv[3], k2[2] = {0.0, 0.0};
-          for (int q = 0; q < 3; q++) {
-            const double l = partial ? lam[d + q] : 1.0;
-            double k0, k1;
-            krow(d + q, k0, k1);
-            dv[q] = (l * k0) * r0 + (l * k1) * r1;
-            k2[0] = k0; k2[1] = k1;
-          }
-          double qn[4];
-          q_feat_boxplus(xs + xZ + 5 * f, dv[0], dv[1], qn);
-          double* xf = xs + xZ + 5 * f;
-          xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
-          xf[4] += dv[2];
-          // running rho-rho diagonal:  P_ii -= Lambda_ii (K_i . W_i)
-          const int ir = d + 2;
-          const double li = lam[ir];
-          const double Lii = partial ? (li + li - li * li) : 1.0;
-          diag[f] -= Lii * (k2[0] * Wp[ir * BLD + 2 * g] + k2[1] * Wp[ir * BLD + 2 * g + 1]);
-        }
-        // the later panel columns follow the update:  P_ic -= Lambda_ic (K_i . W_c)
-        for (int c = 2 * (g + 1); c < 2 * Gn; c++) {
-          const int cr = 16 + 3 * gsl[c >> 1] + (c & 1);
-          const double wc0 = Wp[cr * BLD + 2 * g], wc1 = Wp[cr * BLD + 2 * g + 1], lc = lam[cr];
-#pragma unroll
-          for (int u = 0; u < RPT; u++) {
-            const int i = tid + u * T;
-            if (i < nact) {
-              const double t = kr[u][0] * wc0 + kr[u][1] * wc1;
-              const double li = lam[i];
-              const double Lic = partial ? (lc + li - li * lc) : 1.0;
-              Wp[i * BLD + c] -= Lic * t;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      for (int f = tid; f < len; f += T) {                 // fix_depth (:271) on the state and the running diagonal
+    };
+    auto fix_depth_own = [&]() {                            // fix_depth (:271) on the state and the running diagonal
+      for (int f = tid; f < len; f += T) {
         const int xR = xZ + 5 * f + 4;
         double rho = xs[xR];
         const double reset = 1.0 / (2.0 * prm.min_depth);
@@ -788,8 +690,118 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
         }
         xs[xR] = rho;
       }
+    };
+    publish_pzz(0);   // (own row: written by this thread in the load above)
+    __syncthreads();
+    // ---- 2. the measurements of the group, in order; two barriers each
+    for (int g = 0; g < Gn; g++) {
+      const int slot = gsl[g], wi = gml[g];
+      int* res = result_all ? &result_all[(long)b * M + mbase + wi] : nullptr;
+      const double* R = wR + 4 * wi;                                // column-major 2x2
+      // prediction, innovation, S^-1 and the gate: every thread for itself (uniform data; cheaper than a broadcast + barrier)
+      double zhat[2], Hb[4];
+      {
+        double t1[3], t2[3], zt[3];
+        bearing_frame_fast(xs + xZ + 5 * slot, t1, t2, zt);
+        h_feat_frame(t1, t2, zt, prm, zhat, Hb);
+      }
+      const double h00 = Hb[0], h01 = Hb[1], h10 = Hb[2], h11 = Hb[3];
+      const double r0 = wz[2 * wi] - zhat[0], r1 = wz[2 * wi + 1] - zhat[1];   // residual (vi_ekf_meas.cpp:220)
+      double S[4], Si[4];
+      {   // S = Hb P_zz Hb^T + R
+        const double* pz = pzz + 4 * (g & 1);
+        const double p00 = pz[0], p01 = pz[1], p10 = pz[2], p11 = pz[3];
+        const double w00 = p00 * h00 + p01 * h01, w01 = p00 * h10 + p01 * h11;      // W rows j0, j0+1
+        const double w10 = p10 * h00 + p11 * h01, w11 = p10 * h10 + p11 * h11;
+        S[0] = h00 * w00 + h01 * w10 + R[0];
+        S[1] = h00 * w01 + h01 * w11 + R[2];
+        S[2] = h10 * w00 + h11 * w10 + R[1];
+        S[3] = h10 * w01 + h11 * w11 + R[3];
+      }
+      inv2_fast(S, Si);
+      const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;   // vi_ekf_meas.cpp:234
+      if (mahal > 9.0) {                                   // gate (:235-239): returns before fix_depth
+        if (res && tid == 0) *res = 1;
+        if (i < nact) *reinterpret_cast<double2*>(Wp + i * BLD + 2 * g) = make_double2(0.0, 0.0);
+        publish_pzz(g + 1);
+        __syncthreads();
+        continue;
+      }
+      int bad = 0;
+      double k0 = 0.0, k1 = 0.0;                           // this thread's row of K
+      if (i < nact) {                                      // W = P H^T, K = W S^-1 (:241), NaN guard (:247)
+        const double2 pr = *reinterpret_cast<const double2*>(Wp + i * BLD + 2 * g);
+        const double w0 = pr.x * h00 + pr.y * h01, w1 = pr.x * h10 + pr.y * h11;
+        k0 = w0 * Si[0] + w1 * Si[2]; k1 = w0 * Si[1] + w1 * Si[3];
+        *reinterpret_cast<double2*>(Wp + i * BLD + 2 * g) = make_double2(w0, w1);
+        if (k0 != k0 || k1 != k1) bad = 1;
+      }
+      if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
+      bad = __syncthreads_or(bad);                         // barrier 1: the W pair is complete
+      if (bad) {
+        if (i < nact) *reinterpret_cast<double2*>(Wp + i * BLD + 2 * g) = make_double2(0.0, 0.0);
+      } else {
+        if (tid == 0) { SiL[4 * g + 0] = Si[0]; SiL[4 * g + 1] = Si[2]; SiL[4 * g + 2] = Si[1]; SiL[4 * g + 3] = Si[3]; }
+        // state correction  x <- x [+] (lambda o K r)   (:254-255 / :262-263);  K rows re-formed from W where needed
+        auto krow = [&](int row, double& q0, double& q1) {
+          const double2 w = *reinterpret_cast<const double2*>(Wp + row * BLD + 2 * g);
+          q0 = w.x * Si[0] + w.y * Si[2]; q1 = w.x * Si[1] + w.y * Si[3];
+        };
+        if (tid == T - 1) {                                // (a thread without a feature of its own: T - 1 >= n > len)
+          double dxb[16], xo[17];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const double l = partial ? lam[q] : 1.0;
+            double q0, q1;
+            krow(q, q0, q1);
+            dxb[q] = (l * q0) * r0 + (l * q1) * r1;
+          }
+          body_boxplus_fast(xs, dxb, xo);
+#pragma unroll
+          for (int q = 0; q < 17; q++) xs[q] = xo[q];
+        }
+        for (int f = tid; f < len; f += T) {
+          const int d = 16 + 3 * f;
+          double dv[3], k2[2] = {0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const double l = partial ? lam[d + q] : 1.0;
+            double q0, q1;
+            krow(d + q, q0, q1);
+            dv[q] = (l * q0) * r0 + (l * q1) * r1;
+            k2[0] = q0; k2[1] = q1;
+          }
+          double qn[4];
+          q_feat_boxplus_fast(xs + xZ + 5 * f, dv[0], dv[1], qn);
+          double* xf = xs + xZ + 5 * f;
+          xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
+          xf[4] += dv[2];
+          // running rho-rho diagonal:  P_ii -= Lambda_ii (K_i . W_i)
+          const int ir = d + 2;
+          const double li = lam[ir];
+          const double Lii = partial ? (li + li - li * li) : 1.0;
+          const double2 wr = *reinterpret_cast<const double2*>(Wp + ir * BLD + 2 * g);
+          diag[f] -= Lii * (k2[0] * wr.x + k2[1] * wr.y);
+        }
+        // the later panel columns follow the update:  P_ic -= Lambda_ic (K_i . W_c), this thread's row
+        if (i < nact) {
+          const double li = lam[i];
+          for (int gc = g + 1; gc < Gn; gc++) {
+            const int cr = 16 + 3 * gsl[gc];
+            const double2 wa = *reinterpret_cast<const double2*>(Wp + cr * BLD + 2 * g);
+            const double2 wb = *reinterpret_cast<const double2*>(Wp + (cr + 1) * BLD + 2 * g);
+            const double la = lam[cr], lb = lam[cr + 1];
+            double2 pc = *reinterpret_cast<double2*>(Wp + i * BLD + 2 * gc);
+            pc.x -= (partial ? (la + li - li * la) : 1.0) * (k0 * wa.x + k1 * wa.y);
+            pc.y -= (partial ? (lb + li - li * lb) : 1.0) * (k0 * wb.x + k1 * wb.y);
+            *reinterpret_cast<double2*>(Wp + i * BLD + 2 * gc) = pc;
+          }
+        }
+      }
+      fix_depth_own();                                     // (not gated: runs after a NaN-guarded update too, :271)
+      publish_pzz(g + 1);
       if (res && tid == 0) *res = 0;
-      __syncthreads();
+      __syncthreads();                                     // barrier 2: state, panel and pzz are ready for the next measurement
     }
     // ---- 3. one pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores.
     //      D[r][c] = sum_k W[j0+r][k] K[i0+c][k]:  D's column index (lane & 15) runs along the ROWS of P (contiguous in memory).
