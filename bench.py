@@ -248,7 +248,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("k_step_resident (one fused launch per step: propagate + %d updates, P resident in "
                                     "VGPRs/LDS), median HIP-event duration %.4f ms" % (N, launch_s * 1e3)) if (N <= 50 and args.kernel != 1)
-                                   else ("k_propagate_stream + k_update_feat_blocked (P in HBM, one pass per 8 updates, fp64 MFMA), "
+                                   else ("k_propagate_stream + k_update_feat_blocked (P in HBM, one pass per 16 updates, fp64 MFMA passes in both kernels), "
                                          "median HIP-event duration of the step's launches %.4f ms" % (launch_s * 1e3)),
                          "alg_bytes_per_launch": alg_bytes},
             "nan_filters": n_bad,
