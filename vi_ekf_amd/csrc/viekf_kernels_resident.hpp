@@ -226,57 +226,67 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
     }
     __syncthreads();  // B2q
 
-    // input-noise rows Gd_f = (M_fb G_b + [0 | Gff]) dt  -> Y[.,32..37], times Qu -> X[.,32..37]   (vi_ekf.cpp:302), with
-    //   M_fb = A_fb dt/2 + (A^2)_fb dt^2/6 = Phi_fb / 3 + A_fb dt/6   (A_fb has only the VEL and B_G columns)
-    for (int e = tid; e < nf * 6; e += TW) {
-      const int row = e / 6, k = e - 6 * row, f = row / 3, r = row - 3 * f;
-      const double* fa = S.featA + FEATA * f;
-      const double* phr = Y + row * XK;
-      double g = 0.0;
-#pragma unroll 4
-      for (int c = 0; c < 16; c++) g += phr[c] * S.Gb[c * 6 + k];
-      double ga = 0.0;
+    // Two products share the operand Phi_fb (nf x 16, in Y[.,0..15]) and run on the matrix cores, one 16-row tile per wave
+    // and turn (v_mfma_f64_16x16x4_f64, 4 k-steps each; the VALU form of these loops was LDS-bound, 16 k clk per step):
+    //   Phi_fb G_b   (nf x 6)  -> input-noise rows Gd_f = (M_fb G_b + [0 | Gff]) dt -> Y[.,32..37], times Qu -> X[.,32..37]
+    //                             (vi_ekf.cpp:302), with M_fb = A_fb dt/2 + (A^2)_fb dt^2/6 = Phi_fb / 3 + A_fb dt/6
+    //   Phi_fb P_bb  (nf x 16) -> U = (Phi P)[feat, body] = Phi_fb P_bb + Phi_ff P[feat, body] -> X[.,0..15];
+    //                             V_J = Phi_ff[J] P[J, body] -> Y[.,16..31]
+    // A result lane holds column lr = lane & 15 of rows lk + 4 r (lk = lane >> 4) of the tile.
+    {
+      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+      for (int t = wv; t * 16 < nf; t += TW / 64) {
+        v4f64 accG = {0.0, 0.0, 0.0, 0.0}, accU = {0.0, 0.0, 0.0, 0.0};
+        const double* arow = Y + min(16 * t + lr, nf - 1) * XK;
 #pragma unroll
-      for (int j = 0; j < 3; j++) ga += fa[r * 3 + j] * S.Gb[(dxVEL + j) * 6 + k] + fa[9 + r * 3 + j] * S.Gb[(dxB_G + j) * 6 + k];
-      g = g / 3.0 + ga * dt / 6.0;
-      if (k >= 3) g += fa[27 + r * 3 + (k - 3)];
-      g *= dt;
-      Y[row * XK + 32 + k] = g;
-      X[row * XK + 32 + k] = g * prm.Qu[k];
+        for (int sk = 0; sk < 4; sk++) {
+          const int c = 4 * sk + lk;
+          const double av = arow[c];
+          const double bg = (lr < 6) ? S.Gb[c * 6 + lr] : 0.0;
+          const double bu = Pbb[c * 16 + lr];
+          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bg, accG, 0, 0, 0);
+          accU = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bu, accU, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const int row = 16 * t + lk + 4 * r4;
+          if (row < nf) {
+            const int f = row / 3, r = row - 3 * f;
+            const double* fa = S.featA + FEATA * f;
+            if (lr < 6) {
+              double ga = 0.0;
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+                ga += fa[r * 3 + j] * S.Gb[(dxVEL + j) * 6 + lr] + fa[9 + r * 3 + j] * S.Gb[(dxB_G + j) * 6 + lr];
+              double g = accG[r4] / 3.0 + ga * dt / 6.0;
+              if (lr >= 3) g += fa[27 + r * 3 + (lr - 3)];
+              g *= dt;
+              Y[row * XK + 32 + lr] = g;
+              X[row * XK + 32 + lr] = g * prm.Qu[lr];
+            }
+            double sv = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) sv += phiff[9 * f + r * 3 + m] * Pbc[(3 * f + m) * 16 + lr];
+            X[row * XK + lr] = accU[r4] + sv;    // U
+            Y[row * XK + 16 + lr] = sv;          // V
+          }
+        }
+      }
     }
-    for (int e = tid; e < 96; e += TW) {
+    // (the two small body products go to the LAST waves: the first ones have a second tile below)
+    for (int e = TW - 1 - tid; e < 96; e += TW) {
       const int r = e / 6, k = e % 6;
       double s = 0.0;
 #pragma unroll 4
       for (int c = 0; c < 16; c++) s += Mbb[r * 16 + c] * S.Gb[c * 6 + k];
       Gdb[e] = s * dt;
     }
-    for (int e = tid; e < 256; e += TW) {
+    for (int e = TW - 1 - tid; e < 256; e += TW) {
       const int r = e >> 4, c = e & 15;
       double s = 0.0;
 #pragma unroll 4
       for (int k = 0; k < 16; k++) s += Phibb[r * 16 + k] * Pbb[k * 16 + c];
       T16[e] = s;
-    }
-    // U = (Phi P)[feat, body] -> X[.,0..15];  V_J = Phi_ff[J] P[J, body] -> Y[.,16..31]
-#pragma unroll 1
-    for (int e = tid; e < N * 16; e += TW) {
-      const int I = e >> 4, k = e & 15;
-      double pc[3];
-#pragma unroll
-      for (int m = 0; m < 3; m++) pc[m] = Pbc[(3 * I + m) * 16 + k];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        double su = 0.0;
-        const double* phr = Y + (3 * I + r) * XK;  // Phi_fb[3I+r][0..15]
-#pragma unroll 4
-        for (int c = 0; c < 16; c++) su += phr[c] * Pbb[c * 16 + k];
-        double sv = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; m++) sv += phiff[9 * I + r * 3 + m] * pc[m];
-        X[(3 * I + r) * XK + k] = su + sv;   // U
-        Y[(3 * I + r) * XK + 16 + k] = sv;   // V
-      }
     }
 }
 
@@ -288,32 +298,37 @@ __device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShar
   double* Pbc = S.Pbc;
   double* X = S.X; double* Phibb = S.Phibb; double* Gdb = S.Gdb; double* T16 = S.T16;
     // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
-#pragma unroll 1
-    for (int e = tid; e < nf * 16; e += TW) {   // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]
-      const int row = e >> 4, k = e & 15;
-      const double* xr = X + row * XK;
-      const double* pt = S.PhibbT + k;          // Phi_bb[k][c] = PhibbT[c*16 + k]: conflict-free across the 16 k-lanes
-      double s = 0.0;
+    // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]  -- (nf x 22)(22 x 16) on the matrix cores, one 16-row tile
+    // per wave and turn, 6 k-steps (the last two hold the 6 input-noise columns, zero padded)
+    {
+      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+      for (int t = wv; t * 16 < nf; t += TW / 64) {
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* xr = X + min(16 * t + lr, nf - 1) * XK;
 #pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        const double2 xv = *reinterpret_cast<const double2*>(xr + c);
-        s = fma(xv.x, pt[c * 16], s);
-        s = fma(xv.y, pt[c * 16 + 16], s);
-      }
-      double g = 0.0;
+        for (int sk = 0; sk < 4; sk++) {
+          const int c = 4 * sk + lk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[c], S.PhibbT[c * 16 + lr], acc, 0, 0, 0);
+        }
 #pragma unroll
-      for (int c = 0; c < 6; c += 2) {
-        const double2 xv = *reinterpret_cast<const double2*>(xr + 32 + c);
-        g = fma(xv.x, Gdb[k * 6 + c], g);
-        g = fma(xv.y, Gdb[k * 6 + c + 1], g);
+        for (int sk = 0; sk < 2; sk++) {
+          const int c = 4 * sk + lk;                       // 0..7, the input-noise columns are c < 6
+          const double av = (c < 6) ? xr[32 + c] : 0.0;
+          const double bv = (c < 6) ? Gdb[lr * 6 + c] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const int row = 16 * t + lk + 4 * r4;
+          if (row < nf) Pbc[row * 16 + lr] = acc[r4];
+        }
       }
-      Pbc[e] = s + g;
     }
     for (int e = tid; e < 256; e += TW) {
       const int r = e >> 4, c = e & 15;
       double s = 0.0;
 #pragma unroll 4
-      for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
+      for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * S.PhibbT[k * 16 + c];   // (Phi_bb[c][k]: the transposed copy is conflict-free)
       double g = 0.0;
       for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * prm.Qu[k] * Gdb[c * 6 + k];
       s = s + g;
