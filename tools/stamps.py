@@ -38,6 +38,10 @@ for it in range(8):
           "publish+count %5d | body columns %5d | B1 wait %5d" % (
               it, d(s0 - 1 if it else 10, s0), d(s0, b0 + 1), d(b0 + 1, s0 + 2), d(s0 + 2, s0 + 3),
               d(w0 + 1, q0), d(q0, q0 + 1), d(q0 + 1, w0 + 2), d(w0 + 2, w0 + 3)))
+for it in range(8):
+    b0 = 128 + 4 * it; s0 = 16 + 4 * it
+    print("update %d  service detail: fix_depth %5d | predict+result %5d | poll %5d | sync+gain rows %5d" % (
+        it, d(b0 + 1, b0 + 2), d(b0 + 2, b0 + 3), d(b0 + 3, 48 + it), d(48 + it, s0 + 2)))
 it = 3
 for w in range(7):
     q = 192 + 4 * w

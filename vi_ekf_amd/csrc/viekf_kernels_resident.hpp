@@ -838,14 +838,23 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // Each feature lane keeps its own P_zeta,zeta (2x2) current through the updates, so the lane of the NEXT measurement can
   // form  S = Hb P_zz Hb^T + R,  S^-1  and the gate verdict right after its prediction -- at the END of an iteration.
   // The next iteration then starts directly with the gain rows: no separate innovation phase, two barriers per update.
-  int smp = 0;   // which measurement mailbox holds the CURRENT measurement {Hb, res, S^-1, verdict}
   int m = res_next_valid(S, 0);
   RES_STAMP(S, lane == 0, 9);
   __syncthreads();  // Bp : the workers published Pd (diagonal zeta blocks) and the first measurement's columns
   double pf00 = 0.0, pf01 = 0.0, pf10 = 0.0, pf11 = 0.0;
   if (isfeat) { const double* pd = S.Pd + 4 * lane; pf00 = pd[0]; pf01 = pd[1]; pf10 = pd[2]; pf11 = pd[3]; }
   // prediction + innovation of measurement mm (slot == this lane's feature) into mailbox half `hh`, from registers
-  auto predict = [&](const double* t1, const double* t2, const double* zt, int mm, int hh) {
+  // Uniform per-measurement values {Hb, residual, S^-1, gate}: computed by the lane of the measured feature, handed to the
+  // whole wave with v_readlane (they land in SGPRs; an LDS mailbox cost a store, a wave-level sync and a load on the
+  // critical path of every update).
+  struct Meas { double h0, h1, h2, h3, r0, r1, s0, s1, s2, s3, gate; };
+  auto bcast = [&](double v, int src) -> double {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+  };
+  // prediction + innovation of measurement mm, whose feature is lane `src` (wave-uniform): EVERY lane runs the arithmetic
+  // on its own registers (no divergence; the other lanes' results are discarded), lane src's values are broadcast
+  auto predict = [&](const double* t1, const double* t2, const double* zt, int mm, int src, Meas& o) {
     double zhat[2], Hb[4], Sm[4], Si[4];
     h_feat_frame(t1, t2, zt, prm, zhat, Hb);
     const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mm);
@@ -859,13 +868,10 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     Sm[3] = Hb[2] * w01 + Hb[3] * w11 + R[3];
     inv2_fast(Sm, Si);
     const double mahal = (r0 * Si[0] + r1 * Si[2]) * r0 + (r0 * Si[1] + r1 * Si[3]) * r1;   // vi_ekf_meas.cpp:234
-    double* mb = sm + 16 * hh;
-    *reinterpret_cast<double2*>(mb + 0) = make_double2(Hb[0], Hb[1]);
-    *reinterpret_cast<double2*>(mb + 2) = make_double2(Hb[2], Hb[3]);
-    *reinterpret_cast<double2*>(mb + 4) = make_double2(r0, r1);
-    *reinterpret_cast<double2*>(mb + 6) = make_double2(Si[0], Si[1]);
-    *reinterpret_cast<double2*>(mb + 8) = make_double2(Si[2], Si[3]);
-    mb[10] = (mahal > 9.0) ? 1.0 : 0.0;                                                   // gate (:235-239)
+    o.h0 = bcast(Hb[0], src); o.h1 = bcast(Hb[1], src); o.h2 = bcast(Hb[2], src); o.h3 = bcast(Hb[3], src);
+    o.r0 = bcast(r0, src); o.r1 = bcast(r1, src);
+    o.s0 = bcast(Si[0], src); o.s1 = bcast(Si[1], src); o.s2 = bcast(Si[2], src); o.s3 = bcast(Si[3], src);
+    o.gate = bcast((mahal > 9.0) ? 1.0 : 0.0, src);                                       // gate (:235-239)
   };
   // this lane's quaternion and linear state live in registers for the whole loop (written back once at the end)
   double qn[4] = {qptr[0], qptr[1], qptr[2], qptr[3]};
@@ -883,50 +889,67 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // Also leaves the NaN guard (:247; a NaN in H makes every K row NaN, so testing K covers the H test) and the gate verdict
   // for the workers' next phase.
   const double* stash = S.Praw + 2 * n;
-  const double lamk = (lane < 16) ? S.lam[lane] : 0.0;
-  auto gain_rows = [&](const double* mb, int nanword, int gateword, bool from_stash, int sb, bool swept, int slot,
-                       const double* Kc, double* Kd) {   // Kc: gains of the update just swept, Kd: destination buffer
-    const double* Wc = Kc + 2 * n;
-    double* Wd = Kd + 2 * n;
-    const double2 hA = *reinterpret_cast<const double2*>(mb + 0), hB = *reinterpret_cast<const double2*>(mb + 2);
-    const double2 sA = *reinterpret_cast<const double2*>(mb + 6), sB = *reinterpret_cast<const double2*>(mb + 8);
-    const double gfl = mb[10];
+  const double lraw[3] = {S.lam[rid0], S.lam[rid1], S.lam[rid2]};
+  // The rows are dealt by ROLE (a feature lane its three rows, the attitude lane rows 6..8, a linear body lane its one row),
+  // so a lane's own rows of K and W -- all that its state correction needs in the next phase -- stay in registers.
+  struct Rows { double2 kA, wA, kB, wB, kC; int bad; };
+  const bool three = isfeat || isatt;   // lanes with three distinct rows (the others would write the same row three times)
+  const int ridv[3] = {rid0, rid1, rid2};
+  auto gain_rows = [&](const Meas& q, int nanword, int gateword, bool from_stash, const double2 (&stb)[3], double* Kd,
+                       Rows& o) {
+    double* Wd = Kd + 2 * n;                             // (Kd: destination buffer)
     double2 pr[3];
 #pragma unroll
-    for (int u = 0; u < 3; u++) pr[u] = *reinterpret_cast<const double2*>(S.Praw + 2 * min(lane + 64 * u, n - 1));
-    if (from_stash) {
-      const int k = min(lane, 15);
+    for (int u = 0; u < 3; u++) pr[u] = *reinterpret_cast<const double2*>(S.Praw + 2 * ridv[u]);
+    if (from_stash && !isfeat) { pr[0] = stb[0]; pr[1] = stb[1]; pr[2] = stb[2]; }
+    int bad = 0;
+    double2 wv[3], kv[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const double w0 = pr[u].x * q.h0 + pr[u].y * q.h1, w1 = pr[u].x * q.h2 + pr[u].y * q.h3;
+      const double k0 = w0 * q.s0 + w1 * q.s2, k1 = w0 * q.s1 + w1 * q.s3;
+      wv[u] = make_double2(w0, w1); kv[u] = make_double2(k0, k1);
+      if (u == 0 || three) {
+        *reinterpret_cast<double2*>(Wd + 2 * ridv[u]) = wv[u];
+        *reinterpret_cast<double2*>(Kd + 2 * ridv[u]) = kv[u];
+      }
+      if (k0 != k0 || k1 != k1) bad = 1;
+    }
+    bad = __any(bad);
+    if (lane == 0) { sm[nanword] = bad ? 1.0 : 0.0; sm[gateword] = q.gate; }
+    o.kA = kv[0]; o.wA = wv[0]; o.kB = kv[1]; o.wB = wv[1]; o.kC = kv[2]; o.bad = bad;
+  };
+  // The 16 body rows of the NEXT measurement's columns come from the two stashed rows of that feature (see the worker side),
+  // brought up to date with the rank-2 update being swept in this phase (gains Kc / Wc, `swept` = it is applied).  Everything
+  // this needs is complete at the top of a phase, so it runs there, off the critical path.  (Feature lanes discard it.)
+  auto stash_rows = [&](int sb, bool swept, int slot, const double* Kc, double2 (&o)[3]) {
+    const double* Wc = Kc + 2 * n;
+    const double2 ka = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot));
+    const double2 kb2 = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot + 1));
+    auto one = [&](int u) {
+      const int k = isfeat ? 0 : ridv[u];
       const double2 st = *reinterpret_cast<const double2*>(stash + 32 * sb + 2 * k);   // (P[j0][k], P[j0+1][k]) before ...
       // ... the update with gains K, W -- the same expression, operand for operand, as the workers' body-column sweep
-      const double2 ka = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot));
-      const double2 kb2 = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot + 1));
       const double2 wk = *reinterpret_cast<const double2*>(Wc + 2 * k);
+      const double lamk = lraw[u];
       double r0 = st.x, r1 = st.y;
       if (swept) {
         const double La = partial ? (lamk + lz0 - lz0 * lamk) : 1.0, Lb = partial ? (lamk + lz1 - lz1 * lamk) : 1.0;
         r0 = fma(-La, fma(ka.y, wk.y, ka.x * wk.x), r0);
         r1 = fma(-Lb, fma(kb2.y, wk.y, kb2.x * wk.x), r1);
       }
-      if (lane < 16) pr[0] = make_double2(r0, r1);
-    }
-    int bad = 0;
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-      const int row = lane + 64 * u;
-      const double w0 = pr[u].x * hA.x + pr[u].y * hA.y, w1 = pr[u].x * hB.x + pr[u].y * hB.y;
-      const double k0 = w0 * sA.x + w1 * sB.x, k1 = w0 * sA.y + w1 * sB.y;
-      if (row < n) {
-        *reinterpret_cast<double2*>(Wd + 2 * row) = make_double2(w0, w1);
-        *reinterpret_cast<double2*>(Kd + 2 * row) = make_double2(k0, k1);
-        if (k0 != k0 || k1 != k1) bad = 1;
-      }
-    }
-    bad = __any(bad);
-    if (lane == 0) { sm[nanword] = bad ? 1.0 : 0.0; sm[gateword] = gfl; }
+      o[u] = make_double2(r0, r1);
+    };
+    one(0);
+    if (isatt) { one(1); one(2); }   // (only the attitude lane has three distinct body rows)
   };
-  if (m < M && lane == S.mslot[m]) predict(f1, f2, fz, m, 0);
-  wave_lds_sync();   // the mailbox was written by ONE lane
-  if (m < M) gain_rows(sm, 44, 50, false, 0, false, 0, S.Kt, S.Kt);   // (the first raw columns were published before Bp)
+  Meas cur = {}, nxt = {};
+  Rows crow = {}, nrow = {};
+  if (m < M) {
+    predict(f1, f2, fz, m, __builtin_amdgcn_readfirstlane(S.mslot[m]), cur);
+    const double2 none[3] = {};
+    gain_rows(cur, 44, 50, false, none, S.Kt, crow);   // (the first raw columns were published before Bp)
+  }
   int2 sq = S.mseq[min(m, MCAP - 1)];
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
@@ -936,20 +959,16 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
 
   while (m < M) {
     const int mnext = sq.x, slot_next = sq.y;
-    const double* mbx = sm + 16 * smp;
-    const double2 rr = *reinterpret_cast<const double2*>(mbx + 4);
-    const double gflag = mbx[10];
     // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
     const double* kP = (cnt & 1) ? S.X : S.Kt;   // (double-buffered, see the worker side)
     const double* wP = kP + 2 * n;
-    const double2 kA = *reinterpret_cast<const double2*>(kP + 2 * rid0), wA = *reinterpret_cast<const double2*>(wP + 2 * rid0),
-                  kB = *reinterpret_cast<const double2*>(kP + 2 * rid1), wB = *reinterpret_cast<const double2*>(wP + 2 * rid1),
-                  kC = *reinterpret_cast<const double2*>(kP + 2 * rid2);
-    const double nanw = sm[44 + cnt % 3];
+    const double2 kA = crow.kA, wA = crow.wA, kB = crow.kB, wB = crow.wB, kC = crow.kC;   // (own rows: from registers)
     sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
-    const bool gated = gflag != 0.0;
-    const bool bad = nanw != 0.0;        // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows
-    const double r0 = rr.x, r1 = rr.y;
+    const bool gated = cur.gate != 0.0;
+    const bool bad = crow.bad != 0;      // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows
+    const double r0 = cur.r0, r1 = cur.r1;
+    double2 stb[3] = {};
+    if (slot_next >= 0) stash_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), slot_next, kP, stb);
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
     const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
@@ -986,35 +1005,42 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
     if (lane == 0) sm[40 + par] = 0.0;
-    if (!gated && isfeat && lane < len) {   // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238)
-      double rho = lin;
-      if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
-      if (rho < 0.0) {
-        const double err = rho_reset - rho;
-        S.fixadd[par * N + lane] = err * err;
-        sm[40 + par] = 1.0;
-        rho = rho_reset;
-        flag |= FLAG_NEGDEPTH;
-      } else if (rho > 1e2) {
-        S.fixset[par * N + lane] = 1.0;
-        sm[40 + par] = 1.0;
-        rho = rho_reset;
+    // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238): almost never fires -- one wave-wide test
+    const bool odd_depth = !gated && isfeat && lane < len && !(lin >= 0.0 && lin <= 1e2);
+    if (__any(odd_depth)) {
+      if (odd_depth) {
+        double rho = lin;
+        if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
+        if (rho < 0.0) {
+          const double err = rho_reset - rho;
+          S.fixadd[par * N + lane] = err * err;
+          sm[40 + par] = 1.0;
+          rho = rho_reset;
+          flag |= FLAG_NEGDEPTH;
+        } else if (rho > 1e2) {
+          S.fixset[par * N + lane] = 1.0;
+          sm[40 + par] = 1.0;
+          rho = rho_reset;
+        }
+        lin = rho;
       }
-      lin = rho;
     }
-    if (lane == slot_next) predict(f1, f2, fz, mnext, smp ^ 1);   // next measurement: prediction, S^-1, gate -- all from registers
+    RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 2);
+    if (slot_next >= 0) predict(f1, f2, fz, mnext, __builtin_amdgcn_readfirstlane(slot_next), nxt);   // next measurement, from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
+    RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
     if (slot_next >= 0) {
       // The worker waves publish the next raw feature rows right after their block sweeps, long before this point; the count
       // is polled (never a barrier): the workers wait for this wave only at the barrier below, so the wait cannot deadlock.
       int spins = 0;
       while (*rawcnt < nww * (cnt + 1) && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); spins++; }
-      wave_lds_sync();   // the mailbox was written by ONE lane; the raw columns by other waves (count above)
-      gain_rows(sm + 16 * (smp ^ 1), 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), true, (cnt + 1) & 1, !gated && !bad && !(S.dbg & 1),
-                slot_next, kP, (cnt & 1) ? S.Kt : S.X);
+      RES_STAMP(S, lane == 0 && it_ < 8, 48 + it_);
+      wave_lds_sync();   // the raw columns were written by other waves (count above)
+      gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), true, stb, (cnt & 1) ? S.Kt : S.X, nrow);
     }
+    cur = nxt;
+    crow = nrow;
     par ^= 1;
-    smp ^= 1;
     cnt++;
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 2);
     __syncthreads();  // B1 (the only barrier of an update)
