@@ -170,7 +170,7 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 struct ResInst { int RB, NW, nmin, nmax; };
 const ResInst kResInst[] = {
     {3, 7, 1, 50},
-    {4, 6, 1, 50},   // 4 blocks per thread on 6 worker waves (the service wave alone on its SIMD): measured 4 % slower
+    // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
 
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
@@ -178,7 +178,6 @@ typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const dou
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
     case 0: return k_step_resident<3, 7>;
-    case 1: return k_step_resident<4, 6>;
   }
   return nullptr;
 }
