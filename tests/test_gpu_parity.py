@@ -117,12 +117,13 @@ def test_propagate_only_partial_features_and_qx(N, nfeat):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N", [4, 9])
-def test_update_gating_nan_invalid_and_full_update(N):
-    """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update"""
+@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2)])
+def test_update_gating_nan_invalid_and_full_update(N, kernel):
+    """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update; both kernel
+    families (the grouped streaming update has its own gate / skip paths inside a group)"""
     B = 4
     sc = scene.make_scene(B, N, 1, seed=21, params=dict(use_partial_update=0))
-    g = make_gpu(sc, B, N)
+    g = make_gpu(sc, B, N, kernel=kernel)
     fs = []
     for b in range(B):
         f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
@@ -153,6 +154,45 @@ def test_update_gating_nan_invalid_and_full_update(N):
                 exp[b, m] = fs[b].update(orc.FEAT, z[b, m], sc["R"], True, sl)
     assert exp[0, 1] == 1
     assert (res == exp).all(), (res, exp)
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
+
+
+@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2)])
+def test_fix_depth_inside_the_updates(N, kernel):
+    """fix_depth after an UPDATE (vi_ekf_meas.cpp:271): features that start just in front of the camera's infinity with a
+    large depth variance correlated with the bearing are pushed to rho < 0 by noisy pixels -- the reset, the P(rho,rho) edit and the flag, in the middle
+    of a frame's updates (the grouped update tracks that diagonal separately)"""
+    B = 12
+    sc = scene.make_scene(B, N, 1, seed=77 + N)
+    g = make_gpu(sc, B, N, kernel=kernel)
+    x = g.get_state()
+    P = g.get_covariance()
+    for f in range(0, N, 2):
+        d = 16 + 3 * f
+        x[:, 17 + 5 * f + 4] = 2e-3
+        P[:, d + 2, d + 2] = 4.0
+        P[:, d + 2, d] = P[:, d, d + 2] = 0.1          # depth / bearing correlation: the pixel residual moves rho
+        P[:, d + 2, d + 1] = P[:, d + 1, d + 2] = -0.1
+    g.set_state(x=x, P=P)
+    rng = np.random.default_rng(5)
+    z = sc["z"][0] + rng.normal(0.0, 1.5, sc["z"][0].shape)
+    fs = []
+    for b in range(B):
+        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+        for i in range(N):
+            f.init_feature(sc["pix"][b, i], i)
+        f.x[:] = x[b]
+        f.P[:] = P[b]
+        fs.append(f)
+    res = g.step(sc["u"][0], sc["dt"], z, sc["slot"], sc["R"])
+    hit = 0
+    for b in range(B):
+        ref = fs[b].run_steps(sc["u"][0, b][None], sc["dt"][b], z[b][None], sc["slot"][b], sc["R"])[0]
+        assert (res[b] == ref).all()
+    st = g.get_status()
+    hit = int(((st & 4) != 0).sum())
+    assert hit > 0, "no filter took the negative-depth branch: the test does not test what it says"
     assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
