@@ -155,6 +155,17 @@ int viekf_batch_keep_features(viekf_batch *b, const uint8_t *keep, int32_t *new_
  * of the reference's `geometry` dependency and stays on the caller's side. */
 int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge, viekf_mem where);
 
+/* Read-only evaluations at the current state -- what the reference's log writer records (src/vi_ekf/vi_ekf_log.cpp:6-67):
+ *   eval_xdot:    dx_ of VIEKF::dynamics for the input u [batch][6] (src/vi_ekf/vi_ekf_dyn.cpp:6-134; the batch rotates u by
+ *                 q_b_u, vi_ekf.cpp:265-267), xdot [batch][n], zero past the active features;
+ *   eval_h:       zhat = h(x) of measurement model `type` (src/vi_ekf/vi_ekf_meas.cpp:281-386), zhat [batch][4] (unused entries
+ *                 and filters whose slot is not an active feature: NaN); slot [batch] for QZETA / FEAT / DEPTH / INV_DEPTH;
+ *   get_cov_diag: diag(P) [batch][n] (what log_state writes as the covariance record).
+ * None of them changes the filter. */
+int viekf_batch_eval_xdot(viekf_batch *b, const double *u, double *xdot, viekf_mem where);
+int viekf_batch_eval_h(viekf_batch *b, int32_t type, const int32_t *slot, double *zhat, viekf_mem where);
+int viekf_batch_get_cov_diag(viekf_batch *b, double *diag, viekf_mem where);
+
 /* Bounded device-side history for delayed measurements (the reference rewinds its 250-deep ring of (x,P,t),
  * include/vi_ekf.h:50,156-160, src/vi_ekf/vi_ekf_meas.cpp:45-63).  viekf_batch_history_resize allocates `depth`
  * snapshot slots of the whole batch (depth * batch * (8 n ld + 8 nx) bytes: choose it, the reference's 250 would be
@@ -216,6 +227,12 @@ int viekf_seq_keep_only_features(viekf_seq *s, const int32_t *ids, int32_t count
 int viekf_seq_tracked_features(viekf_seq *s, int32_t *ids /* [batch][num_features] */, int32_t *len /* [batch] */);
 int viekf_seq_status(viekf_seq *s, double *t_now, int32_t *ring_index, int32_t *queued, int32_t *inputs);
 
+/* VIEKF::init_logger / disable_logger, src/vi_ekf/vi_ekf_log.cpp:69-117: opens <root><name>_{ACC,...,INV_DEPTH,state,cov,feat_id,
+ * input,xdot,kf,global_pose}.log and _config.txt / _debug.txt and records filter `filter` of the batch from then on -- the binary
+ * record layouts of log_state (:6-35) and log_measurement (:52-67), i.e. what matlab/plot_ekf.m reads.  The global_pose record
+ * holds the pose relative to the current keyframe node (see viekf_batch_keyframe_reset). */
+int viekf_seq_init_logger(viekf_seq *s, const char *root_filename, const char *ekf_name, int32_t filter);
+int viekf_seq_disable_logger(viekf_seq *s);
 #ifdef __cplusplus
 }
 #endif

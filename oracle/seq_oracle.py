@@ -46,7 +46,19 @@ class SeqOracle:
         self.keyframe_features = []
         self.log = []                       # what would go to cerr
         self.keyframe_edges = []
+        self.rec = None                     # what the reference's log writer would record (enable_records)
         self._save()
+
+    # -- vi_ekf_log.cpp:6-67: the records of log_state / log_measurement, kept as Python lists instead of files ----------
+    def enable_records(self):
+        self.rec = {"state": [], "meas": {}}
+        self._rec_state(0.0, np.zeros(6), np.zeros(self.f.n))        # the constructor's first record, vi_ekf.cpp:154
+
+    def _rec_state(self, t, ub, xdot):
+        ids = list(self.f.feature_ids)
+        idv = np.array([float(ids[i]) if i < len(ids) else -1.0 for i in range(self.f.N)])
+        self.rec["state"].append(dict(t=t, x=self.f.x.copy(), Pd=np.diag(self.f.P).copy(), u=np.asarray(ub).copy(),
+                                      xdot=np.asarray(xdot).copy(), ids=idv))
 
     # -- ring <-> live filter -------------------------------------------------------------------------------------
     def _save(self):
@@ -79,11 +91,14 @@ class SeqOracle:
             self.log.append("propagate backwards")
             return
         self._save()                                        # (x_[i_], P_[i_] stay behind as history)
+        xdot = self.f.dynamics(self.f.x.copy(), ub)[0] if (save_input and self.rec is not None) else None   # dx_ of :293
         self.f.propagate(u, dt)                             # :295-304 (+ fix_depth :311); rotates u itself, like the reference
         ip = (self.i + 1) % self.H
         self.t[ip] = t
         self.i = ip
         self._save()
+        if xdot is not None:                                # :316-317
+            self._rec_state(t, ub, xdot)
 
     # -- vi_ekf_meas.cpp:130-194 ----------------------------------------------------------------------------------------
     def add_measurement(self, t, z, mtype, R, active=False, id=-1, depth=math.nan):
@@ -108,7 +123,14 @@ class SeqOracle:
 
     def _update(self, m):
         m.handled = True                                    # :198
-        return self.f.update(m.type, m.z, m.R, m.active, m.id)
+        zhat = self.f.h(m.type, None, m.id)[0] if self.rec is not None else None
+        res = self.f.update(m.type, m.z, m.R, m.active, m.id)
+        if self.rec is not None and res == orc.MEAS_SUCCESS:   # log_measurement sits at the end of update(), :276
+            r = [self.t[self.i] - self.start_t] + list(m.z) + list(zhat[:m.z.size]) + [1.0 if m.active else 0.0]
+            if m.type in (orc.FEAT, orc.QZETA, orc.DEPTH, orc.INV_DEPTH):
+                r.append(float(m.id))
+            self.rec["meas"].setdefault(m.type, []).append(np.array(r))
+        return res
 
     # -- vi_ekf_meas.cpp:6-127 --------------------------------------------------------------------------------------------
     def handle_measurements(self):

@@ -87,3 +87,31 @@ def test_result_codes_for_bad_inputs():
     assert res[1] == 2 and res[2] == 3        # MEAS_NAN, MEAS_INVALID (slot out of range)
     with pytest.raises(v.ViekfError):
         g.update(orc.PIXEL_VEL, np.zeros((B, 2)), np.eye(2))
+
+
+@pytest.mark.parametrize("N,drag", [(4, 1), (12, 0)])
+def test_read_only_evaluations_for_the_log_writer(N, drag):
+    """viekf_batch_eval_h / eval_xdot / get_cov_diag: zhat of every measurement model, dx_ of the dynamics and diag(P) at
+    the current state (what vi_ekf_log.cpp records), against the oracle's h() / dynamics(); the filter is left untouched"""
+    B = 3
+    sc, g, fs = setup(B, N, 80 + N, dict(use_drag_term=drag))
+    x0, P0 = g.get_state(), g.get_covariance()
+    slot = np.array([0, N - 1, N // 2], dtype=np.int32)
+    dims = {orc.ACC: 2 if drag else 3, orc.ALT: 1, orc.ATT: 4, orc.POS: 3, orc.VEL: 3, orc.QZETA: 4, orc.FEAT: 2,
+            orc.DEPTH: 1, orc.INV_DEPTH: 1}
+    for mtype, d in dims.items():
+        use_slot = mtype in (orc.QZETA, orc.FEAT, orc.DEPTH, orc.INV_DEPTH)
+        zh = g.eval_h(mtype, slot if use_slot else None)
+        ref = np.stack([fs[b].h(mtype, None, int(slot[b]) if use_slot else 0)[0][:d] for b in range(B)])
+        assert_close(zh[:, :d], ref, "zhat type %d" % mtype)
+        assert np.isnan(zh[:, d:]).all()
+    bad = g.eval_h(orc.FEAT, np.array([N + 3, -1, 0], dtype=np.int32))
+    assert np.isnan(bad[0]).all() and np.isnan(bad[1]).all() and not np.isnan(bad[2, :2]).any()
+    u = sc["u"][0]
+    xd = g.eval_xdot(u)
+    q = np.asarray(sc["params"]["q_b_u"], dtype=np.float64)
+    ref = np.stack([fs[b].dynamics(fs[b].x.copy(), np.concatenate([orc.q_rota(q, u[b, 0:3]), orc.q_rota(q, u[b, 3:6])]))[0]
+                    for b in range(B)])
+    assert_close(xd, ref, "xdot")
+    assert_close(g.get_cov_diag(), np.stack([np.diag(f.P) for f in fs]), "diag P")
+    assert np.array_equal(g.get_state(), x0) and np.array_equal(g.get_covariance(), P0)

@@ -15,12 +15,15 @@ def _params(seed, identity_qbu=False):
     return p
 
 
-def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64):
+def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64, log_root=None, log_filter=0):
     import vi_ekf_amd as v
     p = _params(seed, identity_qbu)
     g = v.BatchVIEKF(B, N, dict(p, keyframe_overlap_threshold=0.8, name="seq"))
     sg = v.SeqVIEKF(g, state_hist=hist, meas_hist=200)
     os_ = [so.SeqOracle(orc.OracleFilter(N).init(**p), 0.8, state_hist=hist) for _ in range(B)]
+    if log_root is not None:
+        sg.init_logger(log_root, "ekf", log_filter)
+        os_[log_filter].enable_records()
     rng = np.random.default_rng(seed)
     pix = rng.uniform(120, 480, (B, N, 2))
     R = np.eye(2) * 10.0
@@ -99,3 +102,43 @@ def test_sequencer_keep_only_features_and_keyframe_reset():
         assert_close(edges[b], os_[b].keyframe_edges[-1], "edge")
     assert_close(g.get_state(), np.stack([o.f.x for o in os_]), "x")
     assert_close(g.get_covariance(), np.stack([o.f.P for o in os_]), "P")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delay", [0.0, 0.0105])
+def test_log_writer_matches_reference_records(tmp_path, delay):
+    """viekf_seq_init_logger: the binary files of vi_ekf_log.cpp (record layouts of log_state / log_measurement, what
+    matlab/plot_ekf.m reads) against the same records from the restated plumbing"""
+    B, N, lf = 3, 5, 1
+    root = str(tmp_path) + "/"
+    g, sg, os_, _, _ = _run(B, N, seed=11, delay=delay, steps=40, log_root=root, log_filter=lf)
+    sg.disable_logger()
+    nx, n = 17 + 5 * N, 16 + 3 * N
+    rec = os_[lf].rec
+
+    def load(name, width):
+        a = np.fromfile(root + "ekf_" + name, dtype=np.float64)
+        assert a.size % width == 0, (name, a.size, width)
+        return a.reshape(-1, width)
+
+    st = load("state.log", 1 + nx)
+    assert st.shape[0] == len(rec["state"]) > 10
+    for name, width, key in (("state.log", 1 + nx, "x"), ("cov.log", 1 + n, "Pd"), ("input.log", 7, "u"),
+                             ("xdot.log", 1 + n, "xdot"), ("feat_id.log", 1 + N, "ids")):
+        a = load(name, width)
+        ref = np.stack([np.concatenate([[r["t"]], r[key]]) for r in rec["state"]])
+        assert_close(a, ref, name)
+    gp = load("global_pose.log", 8)
+    ref = np.stack([np.concatenate([[r["t"]], r["x"][0:3], r["x"][6:10]]) for r in rec["state"]])
+    assert_close(gp, ref, "global_pose.log")     # (no keyframe reset in this run: node pose = identity)
+    for mtype, name, width in ((orc.FEAT, "FEAT.log", 1 + 2 + 2 + 1 + 1), (orc.ALT, "ALT.log", 1 + 1 + 1 + 1)):
+        a = load(name, width)
+        ref = np.stack(rec["meas"][mtype])
+        assert a.shape == ref.shape and a.shape[0] >= 4
+        assert_close(a, ref, name)
+    import os
+    for name in ("ACC.log", "kf.log", "debug.txt"):
+        assert os.path.getsize(root + "ekf_" + name) == 0
+    cfg = open(root + "ekf_config.txt").read().splitlines()
+    assert cfg[0].startswith("Test Num: ") and cfg[-1].startswith("min_depth: ") and len(cfg) == 17
+    assert cfg[-2] == "num features: %d" % N

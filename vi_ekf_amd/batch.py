@@ -229,6 +229,31 @@ class BatchVIEKF:
         self._keep = []
         return edge
 
+    def eval_xdot(self, u):
+        """dx_ of VIEKF::dynamics at the current state for the input u [B][6] (reference vi_ekf_dyn.cpp:6-134): [B][n]"""
+        self._keep = []
+        pu, _ = self._arg(u, np.float64, (self.B, 6), None)
+        out = np.zeros((self.B, self.n), dtype=np.float64)
+        capi.check(capi.lib().viekf_batch_eval_xdot(self._h, pu, C.c_void_p(out.ctypes.data), capi.HOST))
+        self._keep = []
+        return out
+
+    def eval_h(self, mtype, slot=None):
+        """zhat = h(x) of a measurement model at the current state (reference vi_ekf_meas.cpp:281-386): [B][4], NaN padded"""
+        self._keep = []
+        ps = None
+        if slot is not None:
+            ps, _ = self._arg(slot, np.int32, (self.B,), None)
+        out = np.zeros((self.B, 4), dtype=np.float64)
+        capi.check(capi.lib().viekf_batch_eval_h(self._h, int(mtype), ps, C.c_void_p(out.ctypes.data), capi.HOST))
+        self._keep = []
+        return out
+
+    def get_cov_diag(self):
+        out = np.zeros((self.B, self.n), dtype=np.float64)
+        capi.check(capi.lib().viekf_batch_get_cov_diag(self._h, C.c_void_p(out.ctypes.data), capi.HOST))
+        return out
+
     def history_resize(self, depth):
         capi.check(capi.lib().viekf_batch_history_resize(self._h, int(depth)))
 

@@ -647,6 +647,70 @@ int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge
   return VIEKF_OK;
 }
 
+// ---- read-only evaluations for the log writer (see the kernels) ----
+int viekf_batch_eval_xdot(viekf_batch* b, const double* u, double* xdot, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || !xdot) return fail(VIEKF_ERR_INVALID, "u / xdot is null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t ub = sizeof(double) * 6 * (size_t)b->B, ob = sizeof(double) * (size_t)b->B * b->n;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(ub) + stage_size(ob))) return rc;
+  const double* d_u = nullptr;
+  if (int rc = in_ptr(b, u, 6 * (size_t)b->B, where, &d_u)) return rc;
+  double* d_o = where == VIEKF_DEVICE ? xdot : static_cast<double*>(stage_take(b, ob));
+  StreamArgs a = make_args(b);
+  const size_t lds = sizeof(double) * (size_t)(b->nxs + 256 + 96 + 16) + sizeof(BodyCtx) + 16;
+  hipLaunchKernelGGL(k_eval_xdot<kThreads>, dim3(b->B), dim3(kThreads), lds, b->stream, a, d_u, d_o);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(xdot, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_eval_h(viekf_batch* b, int32_t type, const int32_t* slot, double* zhat, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!zhat) return fail(VIEKF_ERR_INVALID, "zhat is null");
+  if (type < 0 || type > 9 || type == 7) return fail(VIEKF_ERR_INVALID, "no measurement model for this type");
+  const bool needs_slot = type == 5 || type == 6 || type == 8 || type == 9;
+  if (needs_slot && !slot) return fail(VIEKF_ERR_INVALID, "this measurement model needs a feature slot");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t sb = sizeof(int32_t) * (size_t)b->B, ob = sizeof(double) * 4 * (size_t)b->B;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(sb) + stage_size(ob))) return rc;
+  const int32_t* d_slot = nullptr;
+  if (needs_slot)
+    if (int rc = in_ptr(b, slot, (size_t)b->B, where, &d_slot)) return rc;
+  double* d_o = where == VIEKF_DEVICE ? zhat : static_cast<double*>(stage_take(b, ob));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_eval_h, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, a, type, d_slot, d_o);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(zhat, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_get_cov_diag(viekf_batch* b, double* diag, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!diag) return fail(VIEKF_ERR_INVALID, "diag is null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t ob = sizeof(double) * (size_t)b->B * b->n;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(ob))) return rc;
+  double* d_o = where == VIEKF_DEVICE ? diag : static_cast<double*>(stage_take(b, ob));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_cov_diag, dim3((b->n + 63) / 64, b->B), dim3(64), 0, b->stream, a, d_o);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(diag, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
 static size_t hist_nx(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->nxs; }
 static size_t hist_nP(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->n * b->ld; }
 static double* slot_x(const viekf_batch* b, int slot) { return reinterpret_cast<double*>(reinterpret_cast<char*>(b->h_x) + hist_nx(b) * slot); }

@@ -181,7 +181,7 @@ __device__ __forceinline__ int res_next_valid(const ResShared& S, int from) {
 // Barriers B1p, B2p, B2q inside; the caller continues with B3p.
 template <int TW>
 __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResShared& S, int tid) {
-  const int N = S.N, nf = S.nf;
+  const int nf = S.nf;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc; double* Pbb = S.Pbb;
   double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShar
   const int nf = S.nf;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc;
-  double* X = S.X; double* Phibb = S.Phibb; double* Gdb = S.Gdb; double* T16 = S.T16;
+  double* X = S.X; double* Gdb = S.Gdb; double* T16 = S.T16;
     // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
     // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]  -- (nf x 22)(22 x 16) on the matrix cores, one 16-row tile
     // per wave and turn, 6 k-steps (the last two hold the 6 input-noise columns, zero padded)
@@ -961,7 +961,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const int mnext = sq.x, slot_next = sq.y;
     // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
     const double* kP = (cnt & 1) ? S.X : S.Kt;   // (double-buffered, see the worker side)
-    const double* wP = kP + 2 * n;
     const double2 kA = crow.kA, wA = crow.wA, kB = crow.kB, wB = crow.wB, kC = crow.kC;   // (own rows: from registers)
     sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
     const bool gated = cur.gate != 0.0;

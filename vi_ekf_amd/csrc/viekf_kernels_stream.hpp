@@ -597,7 +597,6 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   const bool partial = prm.use_partial_update != 0;
   unsigned flag = 0;
   constexpr int NWV = T / 64;
-  constexpr int RPT = 1;        // rows per thread in the panel phase (T * RPT >= n: checked on the host)
   const int lane = tid & 63, wave = tid >> 6;
 
   for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
@@ -941,6 +940,87 @@ __device__ __forceinline__ void small_inverse_dev(int r, const double* S, double
       for (int k = i + 1; k < r; k++) s -= a[i * 3 + k] * Si[k * r + j];
       Si[i * r + j] = s / a[i * 3 + i];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Read-only evaluations for the log writer (src/vi_ekf/vi_ekf_log.cpp): what the reference records next to a propagate
+// (xdot = dx_ of VIEKF::dynamics, vi_ekf_dyn.cpp:6-134; the diagonal of P) and next to an update (zhat = h(x),
+// vi_ekf_meas.cpp:281-386).  They do not touch the filter, so the hot kernels carry no logging arguments.
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_eval_xdot(StreamArgs a, const double* __restrict__ u_all, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= a.B) return;
+  double* xs = smem;
+  double* Abb = xs + a.nxs;
+  double* Gb = Abb + 256;
+  double* xdb = Gb + 96;
+  BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
+  const int len = a.len[b];
+  const double* xg = a.x + (long)b * a.nxs;
+  for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
+  __syncthreads();
+  if (tid == 0) {
+    double ub[6];
+    q_rota(a.dp->q_b_u, u_all + (long)b * 6, ub);          // vi_ekf.cpp:265-267
+    q_rota(a.dp->q_b_u, u_all + (long)b * 6 + 3, ub + 3);
+    body_ctx(xs, ub, (*a.dp), *ctx);
+    body_dynamics(*ctx, (*a.dp), xdb, Abb, Gb);
+  }
+  __syncthreads();
+  double* o = out + (long)b * a.n;
+  for (int i = tid; i < a.n; i += T) {
+    double v = 0.0;
+    if (i < 16) v = xdb[i];
+    else {
+      const int f = (i - 16) / 3, q = (i - 16) - 3 * f;
+      if (f < len) {
+        double xd3[3], Afv[9], Afg[9], Aff[9];
+        feature_dynamics(xs + xZ + 5 * f, xs[xZ + 5 * f + 4], *ctx, xd3, Afv, Afg, Aff);
+        v = xd3[q];
+      }
+    }
+    o[i] = v;
+  }
+}
+
+// zhat [B][4] of measurement model `type` at the current state (one thread per filter); unused entries and filters whose
+// slot is out of range get NaN
+__global__ void k_eval_h(StreamArgs a, int type, const int* __restrict__ slot_all, double* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double* xs = a.x + (long)b * a.nxs;
+  const DevParams& prm = *a.dp;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  double zhat[4] = {nan, nan, nan, nan};
+  const bool needs_slot = type == 5 || type == 6 || type == 8 || type == 9;   // QZETA, FEAT, DEPTH, INV_DEPTH
+  const int slot = (needs_slot && slot_all) ? slot_all[b] : 0;
+  if (!needs_slot || (slot >= 0 && slot < a.len[b])) {
+    if (type == 0) {                                          // ACC, vi_ekf_meas.cpp:281-306
+      if (prm.use_drag_term) {
+        const double mu = xs[xMU];
+        zhat[0] = -mu * xs[xVEL] + xs[xB_A]; zhat[1] = -mu * xs[xVEL + 1] + xs[xB_A + 1];
+      } else {
+        const double g[3] = {0.0, 0.0, kGravity}; double gB[3];
+        q_rotp(xs + xATT, g, gB);
+        for (int i = 0; i < 3; i++) zhat[i] = xs[xB_A + i] - gB[i];
+      }
+    } else if (type == 1) zhat[0] = -xs[xPOS + 2];            // ALT
+    else if (type == 2) { for (int i = 0; i < 4; i++) zhat[i] = xs[xATT + i]; }
+    else if (type == 3) { for (int i = 0; i < 3; i++) zhat[i] = xs[xPOS + i]; }
+    else if (type == 4) { for (int i = 0; i < 3; i++) zhat[i] = xs[xVEL + i]; }
+    else if (type == 5) { for (int i = 0; i < 4; i++) zhat[i] = xs[xZ + 5 * slot + i]; }
+    else if (type == 6) { double Hb[4], zh[2]; h_feat(xs + xZ + 5 * slot, prm, zh, Hb); zhat[0] = zh[0]; zhat[1] = zh[1]; }
+    else if (type == 8) zhat[0] = 1.0 / xs[xZ + 5 * slot + 4];
+    else if (type == 9) zhat[0] = xs[xZ + 5 * slot + 4];
+  }
+  for (int i = 0; i < 4; i++) out[(long)b * 4 + i] = zhat[i];
+}
+
+__global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
+  const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
 }
 
 template <int T>

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -50,6 +52,9 @@ struct viekf_seq {
   std::vector<int32_t> next_id;                                    // next_feature_id_ per filter
   std::vector<std::vector<int32_t>> kf_feats;                      // keyframe_features_ per filter
   std::string err;
+  // binary logs of ONE filter of the batch, file for file what VIEKF::init_logger opens (src/vi_ekf/vi_ekf_log.cpp:79-117)
+  std::vector<std::ofstream> log;                                  // empty = logging off
+  int log_filter = 0;
 };
 
 namespace {
@@ -58,6 +63,55 @@ int local_id(const viekf_seq* s, int b, int gid) {                 // vi_ekf_hel
   const auto& v = s->ids[b];
   auto it = std::find(v.begin(), v.end(), gid);
   return it == v.end() ? -1 : (int)(it - v.begin());
+}
+
+// ---- log writer (src/vi_ekf/vi_ekf_log.cpp) ------------------------------------------------------------------------------
+enum { kTotalMeas = 10, LOG_STATE = kTotalMeas, LOG_COV, LOG_FEATURE_IDS, LOG_INPUT, LOG_XDOT, LOG_GLOBAL, LOG_CONF, LOG_KF,
+       LOG_DEBUG, LOG_GLOBAL_POSE, TOTAL_LOGS };                   // include/vi_ekf.h:141-153
+const char* const kMeasNames[kTotalMeas] = {"ACC", "ALT", "ATT", "POS", "VEL", "QZETA", "FEAT", "PIXEL_VEL", "DEPTH",
+                                            "INV_DEPTH"};           // include/vi_ekf.h:340-354
+
+void wr(std::ofstream& f, const double* p, size_t n) { f.write(reinterpret_cast<const char*>(p), sizeof(double) * n); }
+
+// log_state, vi_ekf_log.cpp:6-35: (t, x), (t, diag P), (t, u), (t, dx), (t, ids), (t, pose) of the logged filter.
+// x / Pd / xdot are whole-batch arrays [B][nx] / [B][n] / [B][n]; ub is the logged filter's ROTATED input (or NULL = zeros).
+void log_state(viekf_seq* s, double t, const std::vector<double>& x, const std::vector<double>& Pd, const double* ub,
+               const double* xdot) {
+  const int f = s->log_filter, nx = 17 + 5 * s->N, n = 16 + 3 * s->N;
+  const double zeros6[6] = {0, 0, 0, 0, 0, 0};
+  wr(s->log[LOG_STATE], &t, 1); wr(s->log[LOG_STATE], x.data() + (size_t)f * nx, nx);
+  wr(s->log[LOG_COV], &t, 1); wr(s->log[LOG_COV], Pd.data() + (size_t)f * n, n);
+  wr(s->log[LOG_INPUT], &t, 1); wr(s->log[LOG_INPUT], ub ? ub : zeros6, 6);
+  wr(s->log[LOG_XDOT], &t, 1);
+  if (xdot) wr(s->log[LOG_XDOT], xdot + (size_t)f * n, n);
+  else { std::vector<double> z((size_t)n, 0.0); wr(s->log[LOG_XDOT], z.data(), n); }
+  wr(s->log[LOG_FEATURE_IDS], &t, 1);
+  for (int i = 0; i < s->N; i++) {
+    const double idd = i < (int)s->ids[f].size() ? (double)s->ids[f][i] : -1.0;
+    wr(s->log[LOG_FEATURE_IDS], &idd, 1);
+  }
+  // The reference writes current_node_global_pose_ * (p, q) here; that composition lives in its `geometry` dependency (not
+  // part of this library, see viekf_batch_keyframe_reset): this record holds the pose relative to the current keyframe
+  // node, which is the global pose until the first keyframe reset.
+  const double* xf = x.data() + (size_t)f * nx;
+  wr(s->log[LOG_GLOBAL_POSE], &t, 1); wr(s->log[LOG_GLOBAL_POSE], xf + 0, 3); wr(s->log[LOG_GLOBAL_POSE], xf + 6, 4);
+}
+
+int fetch_state_and_diag(viekf_seq* s, std::vector<double>& x, std::vector<double>& Pd) {
+  x.resize((size_t)s->B * (17 + 5 * s->N));
+  Pd.resize((size_t)s->B * (16 + 3 * s->N));
+  if (int rc = viekf_batch_get_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  return viekf_batch_get_cov_diag(s->core, Pd.data(), VIEKF_HOST);
+}
+
+// Eigen's default stream format of a row vector: coefficients right-aligned to the widest one, separated by one space
+std::string eigen_row(const double* v, int n) {
+  std::vector<std::string> t(n);
+  size_t w = 0;
+  for (int i = 0; i < n; i++) { std::ostringstream o; o << v[i]; t[i] = o.str(); w = std::max(w, t[i].size()); }
+  std::string r;
+  for (int i = 0; i < n; i++) { if (i) r += " "; r += std::string(w - t[i].size(), ' ') + t[i]; }
+  return r;
 }
 
 // numeric core of propagate_state (vi_ekf.cpp:291-311) with ring bookkeeping; `u` is what the caller hands to
@@ -81,10 +135,21 @@ int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
   if (std::fabs(dt) < 1e-6) return VIEKF_OK;                       // :281-283
   if (dt < 0) return VIEKF_OK;                                     // :285-289 ("I won't let you")
   std::vector<double> dts((size_t)B, dt);
+  const bool logging = save_input && !s->log.empty();              // :316-317 (replays are not logged)
+  std::vector<double> xdot;
+  if (logging) {                                                   // dx_ belongs to the state BEFORE the step (:293)
+    xdot.resize((size_t)B * (16 + 3 * s->N));
+    if (int rc = viekf_batch_eval_xdot(s->core, u, xdot.data(), VIEKF_HOST)) return rc;
+  }
   const int ip = (s->i + 1) % s->H;                                // :298: x_[ip], P_[ip] are written from x_[i_], P_[i_] --
   if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), ip, VIEKF_HOST)) return rc;   // the old slot stays as history
   s->i = ip;                                                       // :306
   s->t[s->i] = t;
+  if (logging) {
+    std::vector<double> x, Pd;
+    if (int rc = fetch_state_and_diag(s, x, Pd)) return rc;
+    log_state(s, t, x, Pd, s->u.front().second.data() + 6 * (size_t)s->log_filter, xdot.data());
+  }
   return VIEKF_OK;
 }
 
@@ -99,12 +164,30 @@ int update_entry(viekf_seq* s, SeqMeas& m, std::vector<int32_t>& res) {   // VIE
     if (needs_slot) slot[b] = m.present[b] ? local_id(s, b, m.id[b]) : -1;
     act[b] = m.present[b] ? (m.active ? 1 : 0) : 2;                // 2 = this filter skips the entry altogether
   }
+  const int lf = s->log_filter;
+  const bool logging = !s->log.empty() && m.present[lf] && m.type >= 0 && m.type < kTotalMeas;
+  std::vector<double> zhat;
+  if (logging) {                                                   // zhat_ = h(x) at the state the update starts from (:201-207)
+    zhat.assign((size_t)B * 4, 0.0);
+    if (int rc = viekf_batch_eval_h(s->core, m.type, needs_slot ? slot.data() : nullptr, zhat.data(), VIEKF_HOST)) return rc;
+  }
   int rc;
   if (m.type == VIEKF_FEAT && m.active) {
     rc = viekf_batch_update_feat(s->core, m.z.data(), slot.data(), 1, m.R.data(), 0, res.data(), VIEKF_HOST);
   } else {
     rc = viekf_batch_update(s->core, m.type, m.z.data(), m.zdim, m.R.data(), m.rdim, 0, needs_slot ? slot.data() : nullptr,
                             act.data(), res.data(), VIEKF_HOST);
+  }
+  // log_measurement, vi_ekf_log.cpp:52-67, called at the END of update() (vi_ekf_meas.cpp:276): a gated update returned before
+  if (rc == VIEKF_OK && logging && res[lf] != VIEKF_MEAS_GATED && res[lf] != VIEKF_MEAS_INVALID && res[lf] != VIEKF_MEAS_NAN) {
+    std::ofstream& f = s->log[m.type];
+    const double tt = s->t[s->i] - s->start_t;
+    wr(f, &tt, 1);
+    wr(f, m.z.data() + (size_t)lf * m.zdim, m.zdim);
+    wr(f, zhat.data() + (size_t)lf * 4, m.zdim);
+    const double ac = m.active ? 1.0 : 0.0;
+    wr(f, &ac, 1);
+    if (needs_slot || m.type == 7) { const double idd = (double)m.id[lf]; wr(f, &idd, 1); }
   }
   return rc;
 }
@@ -302,6 +385,52 @@ int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count
     if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), edges, VIEKF_HOST)) return rc;
     }
   if (did_reset) std::memcpy(did_reset, reset.data(), B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_init_logger(viekf_seq* s, const char* root_filename, const char* ekf_name, int32_t filter) {   // vi_ekf_log.cpp:79-117
+  if (!s || !root_filename || !ekf_name || filter < 0 || filter >= s->B) return VIEKF_ERR_INVALID;
+  const std::string base = std::string(root_filename) + ekf_name;
+  s->log.clear();
+  s->log.resize(TOTAL_LOGS);
+  auto open = [&](int i, const std::string& suffix) { s->log[i].open(base + suffix, std::ofstream::out | std::ofstream::trunc); };
+  for (int i = 0; i < kTotalMeas; i++) open(i, std::string("_") + kMeasNames[i] + ".log");
+  open(LOG_STATE, "_state.log"); open(LOG_COV, "_cov.log"); open(LOG_FEATURE_IDS, "_feat_id.log"); open(LOG_CONF, "_config.txt");
+  open(LOG_INPUT, "_input.log"); open(LOG_XDOT, "_xdot.log"); open(LOG_KF, "_kf.log"); open(LOG_DEBUG, "_debug.txt");
+  open(LOG_GLOBAL_POSE, "_global_pose.log");
+  for (int i = 0; i < TOTAL_LOGS; i++)
+    if (i != LOG_GLOBAL && !s->log[i].is_open()) { s->log.clear(); return VIEKF_ERR_INVALID; }   // (LOG_GLOBAL is never opened, :85-97)
+  s->log_filter = filter;
+  std::vector<double> x, Pd;
+  if (int rc = fetch_state_and_diag(s, x, Pd)) { s->log.clear(); return rc; }
+  const int nx = 17 + 5 * s->N, n = 16 + 3 * s->N;
+  const viekf_params& p = s->prm;
+  std::ofstream& c = s->log[LOG_CONF];                              // :100-116, line for line
+  c << "Test Num: " << root_filename << "\n";
+  c << "x0" << eigen_row(x.data() + (size_t)filter * nx, 17) << "\n";
+  c << "P0: " << eigen_row(Pd.data() + (size_t)filter * n, std::min(17, n)) << "\n";   // (the reference prints xZ = 17 entries)
+  c << "P0_feat: " << eigen_row(p.P0_feat, 3) << "\n";
+  c << "Qx: " << eigen_row(p.Qx, 16) << "\n";
+  c << "Qx_feat: " << eigen_row(p.Qx_feat, 3) << "\n";
+  c << "Qu: " << eigen_row(p.Qu, 6) << "\n";
+  c << "q_b_c: " << eigen_row(p.q_b_c, 4) << "\n";
+  c << "p_b_c: " << eigen_row(p.p_b_c, 3) << "\n";
+  c << "lambda: " << eigen_row(p.lambda, 16) << "\n";
+  c << "lambda_feat: " << eigen_row(p.lambda_feat, 3) << "\n";
+  c << "using partial_update: " << (p.use_partial_update != 0) << "\n";
+  c << "using keyframe reset: " << (p.use_keyframe_reset != 0) << "\n";
+  c << "using drag Term: " << (p.use_drag_term != 0) << "\n";
+  c << "keyframe overlap: " << p.keyframe_overlap_threshold << "\n";
+  c << "num features: " << s->N << "\n";
+  c << "min_depth: " << p.min_depth << std::endl;
+  log_state(s, 0.0, x, Pd, nullptr, nullptr);                      // the constructor's first record, vi_ekf.cpp:154
+  return VIEKF_OK;
+}
+
+int viekf_seq_disable_logger(viekf_seq* s) {                       // vi_ekf_log.cpp:69-77
+  if (!s) return VIEKF_ERR_INVALID;
+  for (auto& f : s->log) if (f.is_open()) f.close();
+  s->log.clear();
   return VIEKF_OK;
 }
 

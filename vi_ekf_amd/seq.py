@@ -21,6 +21,8 @@ def _bind():
     L.viekf_seq_keep_only_features.argtypes = [vp, vp, C.c_int32, vp, vp]
     L.viekf_seq_tracked_features.argtypes = [vp, vp, vp]
     L.viekf_seq_status.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.viekf_seq_init_logger.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32]
+    L.viekf_seq_disable_logger.argtypes = [vp]
     L._seq_bound = True
     return L
 
@@ -80,6 +82,13 @@ class SeqVIEKF:
         edges = np.zeros((self.B, 17), dtype=np.float64)
         capi.check(self._L.viekf_seq_keep_only_features(self._h, _p(ids), ids.shape[1], _p(did), _p(edges)))
         return did, edges
+
+    def init_logger(self, root_filename, ekf_name="", filter=0):
+        """binary logs of one filter of the batch in the reference's formats (vi_ekf_log.cpp:79-117; matlab/plot_ekf.m)"""
+        capi.check(self._L.viekf_seq_init_logger(self._h, str(root_filename).encode(), str(ekf_name).encode(), int(filter)))
+
+    def disable_logger(self):
+        capi.check(self._L.viekf_seq_disable_logger(self._h))
 
     def tracked_features(self):
         ids = np.zeros((self.B, self.N), dtype=np.int32)
