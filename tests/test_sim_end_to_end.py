@@ -1,0 +1,142 @@
+"""End-to-end in the shape of the reference's own simulation test (test/vi_ekf_test.cpp:12-61): a simulated multirotor
+drives the estimator through register_imu_cb / register_feat_cb, the estimate is compared with the simulator's truth.
+
+The reference test asserts nothing ("Check error magnitudes" is an empty comment); here the restated estimator must TRACK
+the truth, with errors inside its own covariance -- an independent check that the restatement is a working VI-EKF (the
+simulator integrates the model equations, it shares no code with the oracle), and, on the GPU, that the HIP sequencer
+reproduces the restated plumbing through feature initialisation, loss and re-acquisition.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import seq_oracle as so
+from vi_ekf_amd import sim as S
+
+
+def _params():
+    p = dict(orc.EKF_YAML)
+    p["use_keyframe_reset"] = False     # (a reset re-bases the position; composing it needs the absent `geometry` algebra)
+    return p
+
+
+def _drive(sim, add, keep, handle, propagate):
+    last = []
+
+    def feat_cb(t, pix, ids, R):
+        # The previous frame's measurements are still queued (the reference handles a measurement only once a NEWER input
+        # exists, vi_ekf_meas.cpp:74-75): flush them before features are dropped, or they would be applied to ids that no
+        # longer exist (an out-of-range index in the reference).
+        handle()
+        if set(ids) != set(last):
+            keep(ids)
+            last[:] = list(ids)
+        for i, gid in enumerate(ids):
+            add(t, pix[i], gid, R)
+        handle()
+
+    sim.register_imu_cb(lambda t, z, R: propagate(z, t))
+    sim.register_feat_cb(feat_cb)
+    propagate(sim.imu(), sim.t)          # vi_ekf_test.cpp:57
+
+
+def _errors(x, P, sim):
+    st = sim.state()
+    ep = x[0:3] - st[0:3]
+    ev = x[3:6] - st[7:10]
+    ea = orc.q_boxminus(x[6:10], st[3:7])
+    sd = np.sqrt(np.diag(P)[:9])
+    return ep, ev, ea, sd
+
+
+def test_simulator_follows_its_command():
+    sim = S.Simulator(_params(), num_features=6, seed=2, tmax=6.0)
+    worst = 0.0
+    while sim.run():
+        pc, _ = sim.commanded(sim.t)
+        worst = max(worst, np.linalg.norm(sim.pos - pc))
+        assert abs(np.linalg.norm(sim.q) - 1.0) < 1e-9
+    assert worst < 0.6          # (a PD loop without feed-forward lags the moving set point)
+    z, ids, depth = sim._camera()
+    assert len(ids) == 6 and len(set(ids)) == 6 and (depth > 1.5).all()
+    # the IMU frame convention: q_b_u.rota recovers the body-frame specific force (reference vi_ekf.cpp:265-267)
+    u = sim.imu(noise=False)
+    acc_b = orc.q_rota(np.asarray(sim.p["q_b_u"], float), u[0:3])
+    assert abs(acc_b[2] - (sim.az + sim.accel_bias_[2])) < 1e-9
+
+
+@pytest.mark.parametrize("seed,N", [(1, 8), (4, 12)])
+def test_restated_filter_tracks_simulated_truth(seed, N):
+    p = _params()
+    o = so.SeqOracle(orc.OracleFilter(N).init(**p), 0.8, state_hist=64)
+    sim = S.Simulator(p, num_features=N, seed=seed, tmax=8.0)
+    _drive(sim, lambda t, z, gid, R: o.add_measurement(t, z, orc.FEAT, R, True, gid, float("nan")), o.keep_only_features,
+           o.handle_measurements, o.propagate_state)
+    worst_p = worst_v = worst_a = 0.0
+    inside = total = 0
+    while sim.run():
+        if sim.k % 25 == 0 and sim.t > 1.0:
+            ep, ev, ea, sd = _errors(o.f.x, o.f.P, sim)
+            worst_p, worst_v, worst_a = max(worst_p, np.abs(ep).max()), max(worst_v, np.abs(ev).max()), max(worst_a, np.abs(ea).max())
+            e9 = np.concatenate([ep, ev, ea])
+            inside += int((np.abs(e9) < 3.0 * sd).sum())
+            total += 9
+    assert not o.log, o.log[:3]
+    assert not np.isnan(o.f.x).any()
+    assert worst_p < 0.6 and worst_v < 0.4 and np.degrees(worst_a) < 2.5, (worst_p, worst_v, np.degrees(worst_a))
+    assert inside >= 0.9 * total, (inside, total)       # consistent: the errors live inside the filter's own 3-sigma
+    assert sim.next_feat_id >= N                        # (features were initialised through add_measurement)
+    ba_sd = np.sqrt(np.diag(o.f.P)[9:12])
+    assert (np.abs(o.f.x[10:13] - sim.accel_bias_) < 3.0 * ba_sd).all()   # the bias estimates are consistent as well
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius,check_truth", [(0.35, True), (0.6, False)])
+def test_hip_sequencer_on_the_simulator(radius, check_truth):
+    """The HIP sequencer against the restated plumbing on the simulator's stream.  With the wider circle features leave the
+    image and are re-acquired under new ids: clear_feature compaction, init_feature and the rewind interleave (the
+    reference's ring does not rewind the feature bookkeeping -- the behaviour is restated as it is, so only parity is
+    asserted there)."""
+    import vi_ekf_amd as v
+    N, B = 8, 2
+    p = _params()
+    g = v.BatchVIEKF(B, N, dict(p, keyframe_overlap_threshold=0.8, name="sim"))
+    sg = v.SeqVIEKF(g, state_hist=64, meas_hist=200)
+    o = so.SeqOracle(orc.OracleFilter(N).init(**p), 0.8, state_hist=64)
+    sim = S.Simulator(p, num_features=N, seed=3, tmax=4.0, radius=radius)
+
+    def add(t, z, gid, R):
+        rg = sg.add_measurement(t, np.tile(z, (B, 1)), orc.FEAT, R, True, id=gid)
+        ro = o.add_measurement(t, z, orc.FEAT, R, True, gid, float("nan"))
+        assert (np.asarray(rg) == ro).all()
+
+    def keep(ids):
+        pad = list(ids) + [-1] * (N - len(ids))
+        sg.keep_only_features(np.tile(np.array(pad), (B, 1)))
+        o.keep_only_features(ids)
+
+    def handle():
+        gg = sg.handle_measurements()
+        go = o.handle_measurements()
+        assert gg[0] == go and gg[1] == go
+
+    def propagate(z, t):
+        sg.propagate_state(np.tile(z, (B, 1)), t)
+        o.propagate_state(z, t)
+
+    _drive(sim, add, keep, handle, propagate)
+    while sim.run():
+        pass
+    x, P = g.get_state(), g.get_covariance()
+    assert sg.tracked_features()[0] == list(o.f.feature_ids)
+    if not check_truth:
+        assert sim.next_feat_id > N          # (features were lost and re-acquired)
+    # 1000 propagates, 800 updates and 100 rewinds in closed loop: rounding differences between the two implementations are
+    # amplified by the filter's own dynamics (about 30x per second here), so the bar is the north-star 1e-6 x 100 over the run
+    xo, Po = np.stack([o.f.x] * B), np.stack([o.f.P] * B)
+    assert np.abs(x - xo).max() <= 1e-4 * np.abs(xo).max()
+    assert np.abs(P - Po).max() <= 1e-4 * np.abs(Po).max()
+    assert np.array_equal(x[0], x[1]) and np.array_equal(P[0], P[1])      # identical filters stay bit-identical
+    if check_truth:
+        ep, ev, ea, sd = _errors(x[0], P[0], sim)
+        assert np.abs(ep).max() < 0.6 and np.abs(ev).max() < 0.4 and np.degrees(np.abs(ea).max()) < 2.5

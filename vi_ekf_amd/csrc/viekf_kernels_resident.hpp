@@ -432,9 +432,27 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       const int k = e / nf, row = e - k * nf;
       Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
     }
-    for (int e = tid; e < 256; e += TW) Pbb[(e & 15) * 16 + (e >> 4)] = P[(e & 15) + (long)(e >> 4) * ld];
+    // (the body block is kept EXACTLY symmetric, like every other part of P here -- see sym_diag below: both copies of a pair
+    //  are loaded from the upper triangle)
+    for (int e = tid; e < 256; e += TW) {
+      const int r = e & 15, c = e >> 4;
+      Pbb[r * 16 + c] = P[min(r, c) + (long)max(r, c) * ld];
+    }
   }
 
+  // P is kept EXACTLY symmetric.  Off-diagonal feature blocks and the feature/body strips are symmetric by ownership (one
+  // copy, mirrored at store time); the diagonal blocks (and the body block, in LDS) hold both triangles, and their lower one
+  // is overwritten with the upper one after everything that changes them.  This is not cosmetic: the rank-2 form of the
+  // update,  P -= Lambda o (K W^T)  with W from the COLUMNS of P, equals the reference's Joseph form (vi_ekf_meas.cpp:256-257)
+  // only for symmetric P; on an antisymmetric part A it is  A_zz' = A_zz + K (Hb A_zz Hb^T) K^T  -- growth per update where
+  // the Joseph form contracts -- and rounding-level asymmetry reaches 1e-7 within 3 s of flight (tests/test_sim_end_to_end.py).
+  auto sym_diag = [&]() {
+    if (td_ == 0) {
+#pragma unroll
+      for (int ia = 0; ia < RB; ia++) { pb[ia][3] = pb[ia][1]; pb[ia][6] = pb[ia][2]; pb[ia][7] = pb[ia][5]; }
+    }
+  };
+  sym_diag();
   // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots), kept in SGPRs
   double Lff[9];
   {
@@ -511,12 +529,13 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
           }
       }
     }
+    sym_diag();
     RES_STAMP(S, tid == 0, 69);
     res_prop_body<TW>(a, S, tid);
     par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
-    for (int e = tid; e < 256; e += TW) Pbb[e] = S.Mbb[e];
+    for (int e = tid; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
   }
 
   // block indices of this thread, computed once (symmetric ownership left enough registers to keep them)
@@ -638,6 +657,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
             pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
           }
     }
+    sym_diag();
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
     // ---- (2) the NEXT measurement's raw feature rows (a fix_depth edit touches P(rho,rho) only, never these columns)
     if (slot_next >= 0 && !(S.dbg & 4)) extract_cols(slot_next);
@@ -678,19 +698,24 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
       }
     }
-    if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads
+    if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads.  Element (r, c) and its mirror (c, r) are
+                 // owned by different threads; both form  p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own
+                 // (equal) copies, so the block stays exactly symmetric without any exchange.
       const int ib = it - (TW - 128);
       if (ib >= 0) {
         const int br = ib >> 3, bc2 = (ib & 7) * 2;
-        const double2 bkr = *reinterpret_cast<const double2*>(kP + 2 * br);
-        const double2 bw0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
-        const double2 bw1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
-        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
-        const double blr = S.lam[br];
         double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
+        const double blr = S.lam[br];
+        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
+        const double2 kr = *reinterpret_cast<const double2*>(kP + 2 * br), wr = *reinterpret_cast<const double2*>(wP + 2 * br);
+        const double2 k0 = *reinterpret_cast<const double2*>(kP + 2 * bc2), w0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
+        const double2 k1 = *reinterpret_cast<const double2*>(kP + 2 * bc2 + 2), w1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
         const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
-        bpv.x = fma(-L0, fma(bkr.y, bw0.y, bkr.x * bw0.x), bpv.x);
-        bpv.y = fma(-L1, fma(bkr.y, bw1.y, bkr.x * bw1.x), bpv.y);
+        const bool up0 = br <= bc2, up1 = br <= bc2 + 1;
+        const double2 ka = up0 ? kr : k0, wa = up0 ? w0 : wr;      // (K_lo, W_hi) of element (br, bc2)
+        const double2 kb = up1 ? kr : k1, wb = up1 ? w1 : wr;      // ... of element (br, bc2 + 1)
+        bpv.x = fma(-L0, fma(ka.y, wa.y, ka.x * wa.x), bpv.x);
+        bpv.y = fma(-L1, fma(kb.y, wb.y, kb.x * wb.x), bpv.y);
         *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
       }
     }
@@ -999,7 +1024,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
       pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
       pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
-      pf10 = fma(-L01, fma(kw[7], kw[1], kw[6] * kw[0]), pf10);
+      pf10 = pf01;   // (the workers keep the diagonal blocks exactly symmetric: lower = upper)
       pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
