@@ -120,7 +120,9 @@ int viekf_batch_sync(viekf_batch *b);
 int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
 
 /* state access.  Replaces get_state()/get_covariance()/get_len_features(), include/vi_ekf.h:271-286,
- * and set_x0 / set_imu_bias, src/vi_ekf/vi_ekf.cpp:157-184.  Any pointer may be NULL (skipped). */
+ * and set_x0 / set_imu_bias, src/vi_ekf/vi_ekf.cpp:157-184.  Any pointer may be NULL (skipped).  A covariance handed to
+ * set_state is symmetrised, (P + P^T) / 2: the library keeps P exactly symmetric (the reference's Joseph-form update,
+ * vi_ekf_meas.cpp:256-257, keeps it symmetric to rounding; the rank-2 form used here is equal to it for symmetric P only). */
 int viekf_batch_get_state(viekf_batch *b, double *x, double *P, int32_t *len_features, viekf_mem where);
 int viekf_batch_set_state(viekf_batch *b, const double *x, const double *P, const int32_t *len_features,
                           viekf_mem where);

@@ -128,7 +128,7 @@ bool stream_mfma_ok() {   // VIEKF_STREAM_BLOCKED=0 keeps the kernels without ma
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
   StreamArgs a = make_args(b);
   if (stream_mfma_ok())   // feature/feature part on the fp64 matrix cores
-    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * 9 * (size_t)b->N,
+    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2 + 8 * 16 * 17),
                        b->stream, a, d_u, d_dt);
   else
     hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
@@ -485,9 +485,15 @@ int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, cons
   if (x)
     HIP_TRY(hipMemcpy2DAsync(b->d_x, sizeof(double) * b->nxs, x, sizeof(double) * b->nx, sizeof(double) * b->nx, b->B,
                              kind, b->stream));
-  if (P)
+  if (P) {
     HIP_TRY(hipMemcpy2DAsync(b->d_P, sizeof(double) * b->ld, P, sizeof(double) * b->n, sizeof(double) * b->n,
                              (size_t)b->B * b->n, kind, b->stream));
+    // the kernels keep P exactly symmetric and rely on it (their rank-2 update equals the reference's Joseph form only then)
+    StreamArgs a = make_args(b);
+    const long tot = (long)b->n * b->n;
+    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((tot + 255) / 256), b->B), dim3(256), 0, b->stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   if (len_features) HIP_TRY(hipMemcpyAsync(b->d_len, len_features, sizeof(int32_t) * b->B, kind, b->stream));
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;

@@ -75,6 +75,14 @@ __device__ __forceinline__ void fix_depth_one(double* xs, double* P, int ld, int
 // ------------------------------------------------------------------------------------------------
 // propagate: numeric core of VIEKF::propagate_state (vi_ekf.cpp:262-318)
 // ------------------------------------------------------------------------------------------------
+// LDS written by some lanes of a wave and read by others of the SAME wave: order the accesses (the compiler treats lanes as
+// independent threads and may otherwise move the loads above the stores)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // MF = true: the feature/feature part runs on the fp64 matrix cores (see the pass at the end); otherwise one 3x3 block per thread.
 template <int T, bool MF>
 __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const double* __restrict__ u_all,
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   double* xdb = T16 + 256;              // 16
   BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
   double* Dl = xdb + 16 + (sizeof(BodyCtx) + 7) / 8;   // [N][9] Phi_ff blocks (MF only)
+  double* Tr = Dl + 9 * a.N + (a.N & 1);              // [T / 64][16 x 17] transpose tiles (MF only)
 
   double* xg = a.x + (long)b * a.nxs;
   double* P = a.P + (long)b * n * ld;
@@ -248,28 +257,28 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   __syncthreads();
 
   // ---- write P+ : body block
+  // P+ is written EXACTLY symmetric (every pair gets one value): the update kernels' rank-2 form equals the reference's
+  // Joseph form only for symmetric P and amplifies an antisymmetric part instead of damping it (see the fused kernel's
+  // sym_diag), so rounding-level asymmetry must not be allowed to build up over a flight.
   for (int e = tid; e < 256; e += T) {
-    const int r = e >> 4, c = e & 15;
+    const int r = min(e >> 4, e & 15), c = max(e >> 4, e & 15);   // the (lower index, higher index) expression for both copies
     double s = 0.0;
     for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * Phibb[c * 16 + k];
     double g = 0.0;
     for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * a.dp->Qu[k] * Gdb[c * 6 + k];
     s = s + g;
     if (r == c) s += a.Qx[r];
-    P[r + (long)c * ld] = s;
+    P[(e >> 4) + (long)(e & 15) * ld] = s;
   }
-  // ---- body/feature cross blocks
+  // ---- body/feature cross blocks (the feature-row copy, mirrored)
   for (int e = tid; e < nf * 16; e += T) {
     const int r = e >> 4, k = e & 15;
-    double s = 0.0, st = 0.0;
-    for (int c = 0; c < 16; c++) {
-      s += U[r * 16 + c] * Phibb[k * 16 + c];
-      st += Phibb[k * 16 + c] * Ut[c * nf + r];
-    }
+    double s = 0.0;
+    for (int c = 0; c < 16; c++) s += U[r * 16 + c] * Phibb[k * 16 + c];
     double g = 0.0;
     for (int q = 0; q < 6; q++) g += gd[(16 + r) * 6 + q] * a.dp->Qu[q] * Gdb[k * 6 + q];
     P[(16 + r) + (long)k * ld] = s + g;
-    P[k + (long)(16 + r) * ld] = st + g;
+    P[k + (long)(16 + r) * ld] = s + g;
   }
   if constexpr (MF) {
     // ---- feature/feature part on the matrix cores.  With D = blockdiag(Phi_ff) the new block is
@@ -293,8 +302,11 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
       const int fp = jp / 3, f = j / 3, F = 16 * sup + fp;
       return (fp == f && F < len) ? Dl[9 * F + (jp - 3 * fp) * 3 + (j - 3 * f)] : 0.0;
     };
+    // Only the super-tiles on and below the diagonal are computed (elements i >= j stored); the upper triangle is filled by
+    // the transpose pass that follows -- P+ is symmetric bit for bit, and P_ff is read once, not twice.
     for (int st = wave; st < nst * nst; st += NWV) {
       const int I = st % nst, J = st / nst;
+      if (I < J) continue;
       const int r0 = 16 + 48 * I, c0 = 16 + 48 * J;
       double pA[3][12];
 #pragma unroll
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
             const int j = c0 + 16 * q + lk + 4 * rg;
-            if (i < nact && j < nact) {
+            if (i < nact && j < nact && i >= j) {
               double v = O[q][aa][rg];
               if (i == j) v += a.Qx[i];
               P[i + (long)j * ld] = v;
@@ -359,10 +371,35 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
           }
         }
     }
+    __syncthreads();   // (this block's stores are visible to it after the barrier)
+    // transpose pass: upper triangle of the feature part <- lower triangle, 16 x 16 tiles through a padded LDS tile per wave
+    // (coalesced on both sides: lanes along the rows of the source tile, then along the rows of the destination tile)
+    {
+      double* tt = Tr + wave * (16 * 17);
+      const int ntf = (nf + 15) >> 4;
+      for (int t = wave; t < ntf * ntf; t += NWV) {
+        const int ti = t % ntf, tj = t / ntf;
+        if (ti < tj) continue;
+        const int i0 = 16 + 16 * ti, j0 = 16 + 16 * tj;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int i = min(i0 + lr, nact - 1), j = min(j0 + lk + 4 * rg, nact - 1);
+          tt[(lk + 4 * rg) * 17 + lr] = P[i + (long)j * ld];          // tt[c][r] = P[i0 + r][j0 + c]
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int jj = j0 + lr, ii = i0 + lk + 4 * rg;               // destination element (row jj, column ii), jj < ii
+          if (jj < ii && ii < nact && jj < nact) P[jj + (long)ii * ld] = tt[lr * 17 + lk + 4 * rg];
+        }
+        wave_lds_fence();
+      }
+    }
   } else {
     // ---- feature/feature 3x3 blocks, in place (each block needs only itself + saved body strips)
     for (int e = tid; e < len * len; e += T) {
       const int I = e % len, J = e / len;
+      if (I < J) continue;                       // (the block below the diagonal is computed, its mirror written with it)
       const int r0 = 16 + 3 * I, c0 = 16 + 3 * J;
       double Pij[9], Mij[9], out[9];
       for (int c = 0; c < 3; c++)
@@ -385,8 +422,12 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
           if (I == J && r == c) s += a.Qx[r0 + r];
           out[r * 3 + c] = s;
         }
+      if (I == J) { out[1] = out[3]; out[2] = out[6]; out[5] = out[7]; }   // diagonal block: upper <- lower
       for (int c = 0; c < 3; c++)
-        for (int r = 0; r < 3; r++) P[(r0 + r) + (long)(c0 + c) * ld] = out[r * 3 + c];
+        for (int r = 0; r < 3; r++) {
+          P[(r0 + r) + (long)(c0 + c) * ld] = out[r * 3 + c];
+          if (I != J) P[(c0 + c) + (long)(r0 + r) * ld] = out[r * 3 + c];
+        }
     }
   }
   // inactive slots: Phi = I and G = 0 there, so only Qx is added (vi_ekf.cpp:139-144,304)
@@ -515,7 +556,11 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
       const long tot = (long)nact * nact;
       for (long e = tid; e < tot; e += T) {
         const int i = (int)(e % nact), j = (int)(e / nact);
-        const double t = K[2 * i] * W[2 * j] + K[2 * i + 1] * W[2 * j + 1];
+        // (i, j) and (j, i) both form K_hi . W_lo from their own, equal, copies: P stays EXACTLY symmetric (this rank-2 form
+        //  equals the reference's Joseph form only for symmetric P, and it amplifies an antisymmetric part -- see the fused
+        //  kernel's sym_diag)
+        const int hi = max(i, j), lo = min(i, j);
+        const double t = K[2 * hi] * W[2 * lo] + K[2 * hi + 1] * W[2 * lo + 1];
         const double li = lam[i], lj = lam[j];
         const double L = partial ? (lj + li - li * lj) : 1.0;
         P[i + (long)j * ld] -= L * t;
@@ -833,14 +878,27 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
           if (t >= nt * nt) break;
           const int ti = t % nt, tj = t / nt;
           const int i0 = 16 * ti, j0t = 16 * tj;
-          v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+          // P stays EXACTLY symmetric: element (i, j) of a lower tile (ti > tj) is  P_ij - L (K_i . W_j);  the mirror tile forms
+          // the same products in the same order with the operand roles swapped (A = K rows of the j range, B = W rows of the
+          // i range), and a diagonal tile runs both and picks per element -- so (i, j) and (j, i) come out bitwise equal.
+          const bool lower = ti > tj, diag_t = ti == tj;
+          v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
           for (int sk = 0; sk < ksteps; sk++) {
             const int c = 4 * sk + lk;                       // this lane's contraction index: column c of pair c >> 1
-            const double av = Wp[(j0t + lr) * BLD + c];
-            const double2 wv = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
+            const double2 wj = *reinterpret_cast<const double2*>(Wp + (j0t + lr) * BLD + (c & ~1));
+            const double2 wi = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
             const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
-            const double bv = wv.x * sv.x + wv.y * sv.y;    // K[i][c], the same expression as in the panel phase
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            const double wjc = (c & 1) ? wj.y : wj.x, wic = (c & 1) ? wi.y : wi.x;
+            const double kjc = wj.x * sv.x + wj.y * sv.y;    // K[.][c], the same expression as in the panel phase
+            const double kic = wi.x * sv.x + wi.y * sv.y;
+            if (lower || diag_t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc, 0, 0, 0);      // K_i . W_j
+            if (!lower) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kjc, wic, acc2, 0, 0, 0);            // K_j . W_i
+          }
+          if (!lower && !diag_t) acc = acc2;
+          if (diag_t) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++)
+              if (i0 + lr < j0t + lk + 4 * rg) acc[rg] = acc2[rg];   // upper triangle of the diagonal tile
           }
           const int i = i0 + lr;
           const double li = lam[min(i, nact - 1)];
@@ -1018,6 +1076,20 @@ __global__ void k_eval_h(StreamArgs a, int type, const int* __restrict__ slot_al
   for (int i = 0; i < 4; i++) out[(long)b * 4 + i] = zhat[i];
 }
 
+// P <- (P + P^T) / 2 of every filter (a covariance handed in through viekf_batch_set_state): the kernels keep P exactly
+// symmetric from then on and rely on it
+__global__ void k_symmetrize(StreamArgs a) {
+  const int b = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B || e >= (long)a.n * a.n) return;
+  const int i = (int)(e % a.n), j = (int)(e / a.n);
+  if (i <= j) return;
+  double* P = a.P + (long)b * a.n * a.ld;
+  const double v = 0.5 * (P[i + (long)j * a.ld] + P[j + (long)i * a.ld]);
+  P[i + (long)j * a.ld] = v;
+  P[j + (long)i * a.ld] = v;
+}
+
 __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
   const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
@@ -1176,8 +1248,9 @@ __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, in
     const long tot = (long)nact * nact;
     for (long e = tid; e < tot; e += T) {
       const int i = (int)(e % nact), j = (int)(e / nact);
+      const int hi = max(i, j), lo = min(i, j);   // (exactly symmetric result, see k_update_feat_stream)
       double t = 0.0;
-      for (int q = 0; q < rdim; q++) t += K[3 * i + q] * W[3 * j + q];
+      for (int q = 0; q < rdim; q++) t += K[3 * hi + q] * W[3 * lo + q];
       const double li = lam[i], lj = lam[j];
       const double L = partial ? (lj + li - li * lj) : 1.0;
       P[i + (long)j * ld] -= L * t;
@@ -1334,6 +1407,12 @@ __global__ __launch_bounds__(T) void k_keyframe_reset(StreamArgs a, const unsign
     P[i + (long)(dxATT + 2) * ld] = a0 * Na[6] + a1 * Na[7] + a2 * Na[8];
     P[i + (long)dxPOS * ld] = 0.0; P[i + (long)(dxPOS + 1) * ld] = 0.0; P[i + (long)(dxPOS + 2) * ld] = 0.0;
   }
+  __syncthreads();
+  // N P N^T of a symmetric P is symmetric; make it so bit for bit (the update kernels rely on it): the attitude rows take
+  // the values of the attitude columns
+  for (int i = tid; i < n; i += T)
+    for (int c = 0; c < 3; c++)
+      if (i < dxATT || i > dxATT + c) P[(dxATT + c) + (long)i * ld] = P[i + (long)(dxATT + c) * ld];
   if (tid == 0) {
     const double cr = cos(roll / 2.0), ct = cos(pitch / 2.0), sr = sin(roll / 2.0), st = sin(pitch / 2.0);
     xg[xPOS] = 0.0; xg[xPOS + 1] = 0.0; xg[xPOS + 2] = 0.0;                                  // :65
