@@ -855,11 +855,21 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
       constexpr int TPI = 4;   // tiles per wave and iteration: their 16 loads of P are in flight together (one tile at a time
                                // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
+      // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a tile
+      // below it also writes its result to the mirror position (32-byte pieces, four per 128-byte line); a diagonal tile
+      // forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
+      const int ntri = nt * (nt + 1) / 2;
+      auto tile_of = [&](int t, int& ti, int& tj) {         // t-th tile of the lower triangle, row by row
+        ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+        tj = t - ti * (ti + 1) / 2;
+      };
       auto load_tiles = [&](int tb, double (&pq)[TPI][4]) {
 #pragma unroll
         for (int q = 0; q < TPI; q++) {
-          const int t = min(tb + q * NWV, nt * nt - 1);   // (clamped, unconditional loads: branch-free, so the compiler can
-          const int ti = t % nt, tj = t / nt;             //  count them exactly instead of draining the queue at every use)
+          int ti, tj;                                      // (clamped, unconditional loads: branch-free, so the compiler can
+          tile_of(min(tb + q * NWV, ntri - 1), ti, tj);    //  count them exactly instead of draining the queue at every use)
           const int i = min(16 * ti + lr, nact - 1);
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
@@ -870,31 +880,31 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       };
       double pv[TPI][4], pn[TPI][4];
       load_tiles(wave, pv);
-      for (int tb = wave; tb < nt * nt; tb += NWV * TPI) {
+      for (int tb = wave; tb < ntri; tb += NWV * TPI) {
         load_tiles(tb + NWV * TPI, pn);   // the next iteration's tiles are on the wire during this one's contraction
 #pragma unroll
         for (int q = 0; q < TPI; q++) {
           const int t = tb + q * NWV;
-          if (t >= nt * nt) break;
-          const int ti = t % nt, tj = t / nt;
+          if (t >= ntri) break;
+          int ti, tj;
+          tile_of(t, ti, tj);
           const int i0 = 16 * ti, j0t = 16 * tj;
-          // P stays EXACTLY symmetric: element (i, j) of a lower tile (ti > tj) is  P_ij - L (K_i . W_j);  the mirror tile forms
-          // the same products in the same order with the operand roles swapped (A = K rows of the j range, B = W rows of the
-          // i range), and a diagonal tile runs both and picks per element -- so (i, j) and (j, i) come out bitwise equal.
-          const bool lower = ti > tj, diag_t = ti == tj;
+          const bool diag_t = ti == tj;
           v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
           for (int sk = 0; sk < ksteps; sk++) {
             const int c = 4 * sk + lk;                       // this lane's contraction index: column c of pair c >> 1
-            const double2 wj = *reinterpret_cast<const double2*>(Wp + (j0t + lr) * BLD + (c & ~1));
+            const double wjc = Wp[(j0t + lr) * BLD + c];
             const double2 wi = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
             const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
-            const double wjc = (c & 1) ? wj.y : wj.x, wic = (c & 1) ? wi.y : wi.x;
-            const double kjc = wj.x * sv.x + wj.y * sv.y;    // K[.][c], the same expression as in the panel phase
-            const double kic = wi.x * sv.x + wi.y * sv.y;
-            if (lower || diag_t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc, 0, 0, 0);      // K_i . W_j
-            if (!lower) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kjc, wic, acc2, 0, 0, 0);            // K_j . W_i
+            const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c], the same expression as in the panel phase
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc, 0, 0, 0);                          // K_i . W_j
+            if (diag_t) {                                    // (wave-uniform)
+              const double2 wj = *reinterpret_cast<const double2*>(Wp + (j0t + lr) * BLD + (c & ~1));
+              const double wic = (c & 1) ? wi.y : wi.x;
+              const double kjc = wj.x * sv.x + wj.y * sv.y;
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kjc, wic, acc2, 0, 0, 0);                      // K_j . W_i
+            }
           }
-          if (!lower && !diag_t) acc = acc2;
           if (diag_t) {
 #pragma unroll
             for (int rg = 0; rg < 4; rg++)
@@ -915,12 +925,16 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
 #pragma unroll
         for (int q = 0; q < TPI; q++) {
           const int t = tb + q * NWV;
-          const int ti = t % nt, tj = t / nt;
+          int ti, tj;
+          tile_of(min(t, ntri - 1), ti, tj);
           const int i = 16 * ti + lr;
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
             const int j = 16 * tj + lk + 4 * rg;
-            if (t < nt * nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
+            if (t < ntri && i < nact && j < nact) {
+              P[i + (long)j * ld] = pv[q][rg];
+              if (ti != tj) P[j + (long)i * ld] = pv[q][rg];   // the mirror tile
+            }
           }
         }
 #pragma unroll
