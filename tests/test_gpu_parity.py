@@ -318,3 +318,23 @@ def test_more_measurements_than_one_launch_holds(N, M, kernel):
                 assert res[b, k] == -1
     assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
+
+
+@pytest.mark.parametrize("N,steps,kernel", [(12, 400, 1), (12, 400, 2), (50, 120, 2)])
+def test_long_run_stays_at_parity_and_symmetric(N, steps, kernel):
+    """hundreds of steps (20 k updates at N=50..12): the covariance stays symmetric bit for bit and the distance to the oracle
+    does not grow beyond the rounding level (the rank-2 update form amplifies any asymmetry of P -- DESIGN section 3 -- which a
+    handful of steps does not show)"""
+    B = 2
+    sc = scene.make_scene(B, N, steps, seed=11 + N)
+    g = make_gpu(sc, B, N, kernel=kernel)
+    f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+    for i in range(N):
+        f.init_feature(sc["pix"][0, i], i)
+    for s in range(steps):
+        g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+        f.run_steps(sc["u"][s, 0][None], sc["dt"][0], sc["z"][s, 0][None], sc["slot"][0], sc["R"])
+    x, P = g.get_state(), g.get_covariance()
+    assert np.array_equal(P, P.transpose(0, 2, 1))
+    assert np.abs(x[0] - f.x).max() <= 1e-8 * np.abs(f.x).max()
+    assert np.abs(P[0] - f.P).max() <= 1e-8 * np.abs(f.P).max()
