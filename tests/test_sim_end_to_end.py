@@ -91,8 +91,9 @@ def test_restated_filter_tracks_simulated_truth(seed, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("radius,check_truth,kernel", [(0.35, True, 2), (0.35, True, 1), (0.6, False, 2), (0.6, False, 1)])
-def test_hip_sequencer_on_the_simulator(radius, check_truth, kernel):
+@pytest.mark.parametrize("radius,check_truth,kernel,kfr", [(0.35, True, 2, False), (0.35, True, 1, False), (0.6, False, 2, False),
+                                                          (0.6, False, 1, False), (0.6, False, 2, True), (0.6, False, 1, True)])
+def test_hip_sequencer_on_the_simulator(radius, check_truth, kernel, kfr):
     """The HIP sequencer against the restated plumbing on the simulator's stream.  With the wider circle features leave the
     image and are re-acquired under new ids: clear_feature compaction, init_feature and the rewind interleave (the
     reference's ring does not rewind the feature bookkeeping -- the behaviour is restated as it is, so only parity is
@@ -100,6 +101,7 @@ def test_hip_sequencer_on_the_simulator(radius, check_truth, kernel):
     import vi_ekf_amd as v
     N, B = 8, 2
     p = _params()
+    p["use_keyframe_reset"] = kfr       # (with resets: parity only -- the position is re-based at every keyframe)
     g = v.BatchVIEKF(B, N, dict(p, keyframe_overlap_threshold=0.8, name="sim"))
     g.set_kernel(kernel)
     sg = v.SeqVIEKF(g, state_hist=64, meas_hist=200)
@@ -132,6 +134,8 @@ def test_hip_sequencer_on_the_simulator(radius, check_truth, kernel):
     assert sg.tracked_features()[0] == list(o.f.feature_ids)
     if not check_truth:
         assert sim.next_feat_id > N          # (features were lost and re-acquired)
+    if kfr:
+        assert len(o.keyframe_edges) > 0     # (and keyframe resets happened)
     # 1000 propagates, 800 updates and 100 rewinds in closed loop.  This test is what caught the one real numerical defect of
     # the kernels: their rank-2 update form amplifies any asymmetry of P (the reference's Joseph form damps it), and
     # rounding-level asymmetry grew to 1e-7 (fused kernel) or blew up (streaming kernels) within 3 s.  P is now exactly
