@@ -338,3 +338,43 @@ def test_long_run_stays_at_parity_and_symmetric(N, steps, kernel):
     assert np.array_equal(P, P.transpose(0, 2, 1))
     assert np.abs(x[0] - f.x).max() <= 1e-8 * np.abs(f.x).max()
     assert np.abs(P[0] - f.P).max() <= 1e-8 * np.abs(f.P).max()
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("off", [60.0, 200.0, 420.0])
+def test_large_corrections(kernel, off):
+    """a wide prior and a far-off (but not gated) pixel: rotation-vector corrections of ~0.1, ~0.3 and ~0.7 rad, i.e. every
+    branch of the small-angle / series / library quaternion exponential of the fused kernel, against the oracle"""
+    B, N = 3, 6
+    sc = scene.make_scene(B, N, 1, seed=41)
+    g = make_gpu(sc, B, N, kernel=kernel)
+    x, P = g.get_state(), g.get_covariance()
+    for f in range(N):
+        d = 16 + 3 * f
+        P[:, d, d] = 0.2
+        P[:, d + 1, d + 1] = 0.2
+    for k in (6, 7, 8):
+        P[:, k, k] = 0.3
+    g.set_state(x=x, P=P)
+    fs = []
+    for b in range(B):
+        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+        for i in range(N):
+            f.init_feature(sc["pix"][b, i], i)
+        f.x[:] = x[b]
+        f.P[:] = P[b]
+        fs.append(f)
+    z = sc["z"][0].copy()
+    z[:, 0, 0] += off
+    z[:, 3, 1] -= 0.8 * off
+    res = g.update_feat(z, sc["slot"], sc["R"])
+    x0 = x.copy()
+    for b in range(B):
+        for m in range(N):
+            r = fs[b].update(orc.FEAT, z[b, m], sc["R"], True, int(sc["slot"][b, m]))
+            assert r == res[b, m]
+    assert (res[:, 0] == 0).all()                      # (not gated: the prior is wide enough)
+    moved = np.abs(np.stack([f.x for f in fs]) - x0).max()
+    assert moved > 0.02 * off / 60.0                   # the correction really is large
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
+    assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
