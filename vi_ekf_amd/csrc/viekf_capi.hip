@@ -167,9 +167,11 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 
 // Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the worker thread
 // grid is TR = ceil(N/RB) block-rows x TD = N/2 + 1 wrapped diagonals and must fit NW*64 threads.
-struct ResInst { int RB, NW, nmin, nmax; };
+struct ResInst { int RB, NW, nmin, nmax, max_lds_kb; };
 const ResInst kResInst[] = {
-    {3, 7, 1, 50},
+    {3, 2, 1, 25, 80},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
+                     // runs under the other's sweeps
+    {3, 7, 1, 50, 160},
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
 
@@ -177,7 +179,8 @@ typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const dou
                              const double*, long, long, int*);
 res_kernel_t res_kernel(int inst) {
   switch (inst) {
-    case 0: return k_step_resident<3, 7>;
+    case 0: return k_step_resident<3, 2>;
+    case 1: return k_step_resident<3, 7>;
   }
   return nullptr;
 }
@@ -193,7 +196,7 @@ int setup_resident(viekf_batch* b) {
     if (TR * TC > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
-    if (lds > 160 * 1024) continue;
+    if (lds > (size_t)r.max_lds_kb * 1024) continue;
     if (L.Pbb - L.X < 4 * b->n) continue;   // the second gain-row buffer lives in the propagate-only scratch starting at X
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
