@@ -197,6 +197,11 @@ int setup_resident(viekf_batch* b) {
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > (size_t)r.max_lds_kb * 1024) continue;
+    if (r.NW == 2 && !force) {   // two small workgroups per CU only pay when the batch fills the CUs more than once
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
+      if (b->B <= cus) continue;
+    }
     if (L.Pbb - L.X < 4 * b->n) continue;   // the second gain-row buffer lives in the propagate-only scratch starting at X
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
