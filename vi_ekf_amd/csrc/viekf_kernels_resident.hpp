@@ -506,8 +506,11 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     RES_STAMP(S, tid == 0, 68);
     // ---- register-tiled contraction  P[I,J] += X_I Y_J^T  (K = 38)
+    // (Phi_fb has no POS columns -- nothing depends on the position, vi_ekf_dyn.cpp:55-71 -- so Y[.,0..1] and X[.,16..17] are
+    //  exactly zero: those two column pairs are skipped)
 #pragma unroll 1
-    for (int k = 0; k < XK; k += 2) {
+    for (int k = 2; k < XK; k += 2) {
+      if (k == 16) continue;
       const int tr = opaque(tr_), td = opaque(td_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {

@@ -35,14 +35,13 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // workspace carve-up (doubles) for one filter
 struct WsLayout {
-  long phi_fb, phi_ff, gd, U, Ut, pbr, pbc, Xw, Yw, total;
+  long phi_fb, phi_ff, gd, U, pbr, pbc, Xw, Yw, total;
   __host__ __device__ WsLayout(int N, int n) {
     long o = 0;
     phi_fb = o; o += 3L * N * 16;   // [3N][16]
     phi_ff = o; o += 9L * N;        // [N][9]
     gd = o;     o += 6L * n;        // [n][6]
     U = o;      o += 3L * N * 16;   // [3N][16]   (Phi P)[feat rows, body cols]
-    Ut = o;     o += 16L * 3 * N;   // [16][3N]   (P Phi^T)[body rows, feat cols]
     pbr = o;    o += 16L * n;       // [16][n]    copy of P[body rows, :]
     pbc = o;    o += 16L * n;       // [16][n]    copy of P[:, body cols], stored [k][i]
     const long nfp = ((3L * N + 47) / 48) * 48;
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   double* phi_ff = ws + L.phi_ff;
   double* gd = ws + L.gd;
   double* U = ws + L.U;
-  double* Ut = ws + L.Ut;
   double* pbr = ws + L.pbr;
   double* pbc = ws + L.pbc;
 
@@ -216,24 +214,18 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     for (int i = 0; i < 17; i++) xs[i] = xo[i];
   }
 
-  // ---- U = (Phi P)[feat, body],  Ut = (P Phi^T)[body, feat],  T16 = Phi_bb P_bb
+  // ---- U = (Phi P)[feat, body]  (its mirror (P Phi^T)[body, feat] is not formed: P+ is written symmetric),  T16 = Phi_bb P_bb
   for (int e = tid; e < nf * 16; e += T) {
     const int r = e >> 4, k = e & 15, I = r / 3, rr = r - 3 * I;
-    double s = 0.0, st = 0.0;
-    for (int c = 0; c < 16; c++) {
-      const double ph = phi_fb[r * 16 + c];
-      s += ph * Pbb[c * 16 + k];
-      st += Pbb[k * 16 + c] * ph;
-    }
+    double s = 0.0;
+    for (int c = 0; c < 16; c++) s += phi_fb[r * 16 + c] * Pbb[c * 16 + k];
     double vt = 0.0;
     for (int m = 0; m < 3; m++) {
       const double pf = phi_ff[9 * I + rr * 3 + m];
       s += pf * pbc[k * n + 16 + 3 * I + m];
       vt += pbr[k * n + 16 + 3 * I + m] * pf;
     }
-    st += vt;
     U[r * 16 + k] = s;
-    Ut[k * nf + r] = st;
     if (MF) {
       // rows of the low-rank factors:  P+_ff - D P_ff D^T = U Phi_fb^T + Phi_fb (P_bf D^T) + (Gd Qu) Gd^T = Xw Yw^T
       double* xr = ws + L.Xw + (long)r * WK;
