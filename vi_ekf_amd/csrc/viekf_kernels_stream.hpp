@@ -845,24 +845,27 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       const int nt = (nact + 15) >> 4;
       const int lr = lane & 15, lk = lane >> 4;
       const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
-      constexpr int TPI = 4;   // tiles per wave and iteration: their 16 loads of P are in flight together (one tile at a time
+      constexpr int TPI = 8;   // tiles per wave and unit: their 32 loads of P are in flight together (one tile at a time
                                // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
       // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a tile
       // below it also writes its result to the mirror position (32-byte pieces, four per 128-byte line); a diagonal tile
       // forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
-      const int ntri = nt * (nt + 1) / 2;
-      auto tile_of = [&](int t, int& ti, int& tj) {         // t-th tile of the lower triangle, row by row
-        ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while (ti * (ti + 1) / 2 > t) ti--;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-        tj = t - ti * (ti + 1) / 2;
+      // Work unit of a wave: TPI vertically adjacent tiles of one column block (rows 16 ti0 .. +127): its loads cover 1024
+      // contiguous bytes per column (HBM likes long runs: 128-byte runs scattered over the matrix reached 2.8 TB/s).  Units
+      // are numbered column block by column block over the lower triangle and dealt to the waves round-robin.
+      struct Unit { int tj, ti0; };
+      auto next_unit = [&](Unit u, int steps) {            // advance `steps` units (past the end: tj == nt)
+        for (int s2 = 0; s2 < steps && u.tj < nt; s2++) {
+          u.ti0 += TPI;
+          if (u.ti0 >= nt) { u.tj++; u.ti0 = u.tj; }
+        }
+        return u;
       };
-      auto load_tiles = [&](int tb, double (&pq)[TPI][4]) {
-#pragma unroll
+      auto load_tiles = [&](Unit u, double (&pq)[TPI][4]) {
+        const int tj = min(u.tj, nt - 1);                  // (clamped, unconditional loads: branch-free, so the compiler can
+#pragma unroll                                             //  count them exactly instead of draining the queue at every use)
         for (int q = 0; q < TPI; q++) {
-          int ti, tj;                                      // (clamped, unconditional loads: branch-free, so the compiler can
-          tile_of(min(tb + q * NWV, ntri - 1), ti, tj);    //  count them exactly instead of draining the queue at every use)
-          const int i = min(16 * ti + lr, nact - 1);
+          const int i = min(16 * (u.ti0 + q) + lr, nact - 1);
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
             const int j = min(16 * tj + lk + 4 * rg, nact - 1);
@@ -870,17 +873,17 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
           }
         }
       };
-      double pv[TPI][4], pn[TPI][4];
-      load_tiles(wave, pv);
-      for (int tb = wave; tb < ntri; tb += NWV * TPI) {
-        load_tiles(tb + NWV * TPI, pn);   // the next iteration's tiles are on the wire during this one's contraction
+      double pv[TPI][4];
+      Unit u = next_unit(Unit{0, 0}, wave);
+      while (u.tj < nt) {
+        load_tiles(u, pv);                // (the SIMD's other wave computes meanwhile; an explicit prefetch of the next unit
+        const Unit un = next_unit(u, NWV);   //  did not pay for its registers)
+        const int tj = u.tj, j0t = 16 * tj;
 #pragma unroll
         for (int q = 0; q < TPI; q++) {
-          const int t = tb + q * NWV;
-          if (t >= ntri) break;
-          int ti, tj;
-          tile_of(t, ti, tj);
-          const int i0 = 16 * ti, j0t = 16 * tj;
+          const int ti = u.ti0 + q;
+          if (ti >= nt) break;
+          const int i0 = 16 * ti;
           const bool diag_t = ti == tj;
           v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
           for (int sk = 0; sk < ksteps; sk++) {
@@ -916,23 +919,18 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
         }
 #pragma unroll
         for (int q = 0; q < TPI; q++) {
-          const int t = tb + q * NWV;
-          int ti, tj;
-          tile_of(min(t, ntri - 1), ti, tj);
+          const int ti = u.ti0 + q;
           const int i = 16 * ti + lr;
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
             const int j = 16 * tj + lk + 4 * rg;
-            if (t < ntri && i < nact && j < nact) {
+            if (ti < nt && i < nact && j < nact) {
               P[i + (long)j * ld] = pv[q][rg];
               if (ti != tj) P[j + (long)i * ld] = pv[q][rg];   // the mirror tile
             }
           }
         }
-#pragma unroll
-        for (int q = 0; q < TPI; q++)
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) pv[q][rg] = pn[q][rg];
+        u = un;
       }
     }
     __syncthreads();
