@@ -69,6 +69,7 @@ typedef enum viekf_meas_type {
 #define VIEKF_FLAG_NAN 1u            /* NaNsInTheHouse */
 #define VIEKF_FLAG_BLOWING_UP 2u     /* BlowingUp (> 1e6) */
 #define VIEKF_FLAG_NEGATIVE_DEPTH 4u /* NegativeDepth (seen before fix_depth repaired it) */
+#define VIEKF_FLAG_INTERNAL 8u       /* the fused kernel's in-workgroup hand-over timed out: this filter's step is not to be trusted */
 
 /* The keys VIEKF::load reads (reference src/vi_ekf/vi_ekf.cpp:114-131, params/ekf.yaml). */
 typedef struct viekf_params {

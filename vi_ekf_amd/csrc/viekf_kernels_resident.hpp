@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       // is polled (never a barrier): the workers wait for this wave only at the barrier below, so the wait cannot deadlock.
       int spins = 0;
       while (*rawcnt < nww * (cnt + 1) && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); spins++; }
+      if (spins >= (1 << 22)) flag |= FLAG_INTERNAL;   // (never seen; a bounded wait that gives up must say so)
       RES_STAMP(S, lane == 0 && it_ < 8, 48 + it_);
       wave_lds_sync();   // the raw columns were written by other waves (count above)
       gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), true, stb, (cnt & 1) ? S.Kt : S.X, nrow);

@@ -51,7 +51,7 @@ struct WsLayout {
   }
 };
 
-constexpr unsigned FLAG_NAN = 1u, FLAG_BLOWUP = 2u, FLAG_NEGDEPTH = 4u;
+constexpr unsigned FLAG_NAN = 1u, FLAG_BLOWUP = 2u, FLAG_NEGDEPTH = 4u, FLAG_INTERNAL = 8u;
 
 // fix_depth (vi_ekf_helper.cpp:128-156) for feature i of the block's filter; xs is the LDS copy of x
 __device__ __forceinline__ void fix_depth_one(double* xs, double* P, int ld, int i, const DevParams& p, unsigned& flag) {
