@@ -207,6 +207,29 @@ def main():
         cadence = {"imu_steps_per_s": B * 25 * cyc / tc, "frames_per_s": B * 3 * cyc / tc,
                    "what": "25 propagates : 3 frames of %d feature updates, %d cycles" % (N, cyc)}
 
+    # ... and the reference's own CPU-runnable case (BASELINE configs[0]): ONE filter, N_feat = 12, step latency
+    single = None
+    if world == 1 and not args.no_secondary:
+        try:
+            sc1 = scene.make_scene(1, 12, 8, seed=5)
+            g1 = v.BatchVIEKF(1, 12, sc1["params"], device=dev_index)
+            g1.use_torch_stream()
+            for i in range(12):
+                g1.init_feature(sc1["pix"][:, i, :].copy(), np.full(1, np.nan))
+            du, dz = torch.tensor(sc1["u"], device=dev), torch.tensor(sc1["z"], device=dev)
+            ddt, dsl, dR1 = torch.tensor(sc1["dt"], device=dev), torch.tensor(sc1["slot"], device=dev), torch.tensor(sc1["R"], device=dev)
+            for k in range(20):
+                g1.step(du[k % 8], ddt, dz[k % 8], dsl, dR1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(400):
+                g1.step(du[k % 8], ddt, dz[k % 8], dsl, dR1)
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t1) / 400
+            single = {"ms_per_step": t1 * 1e3, "steps_per_s": 1.0 / t1, "what": "batch=1, N_feat=12, one fused launch per step"}
+        except Exception as e:   # (a secondary number must never cost the primary one)
+            single = {"error": str(e)[:200]}
+
     # per-launch duration of the step's kernels from HIP events on the launch stream
     launch_ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
     launch_s = float(np.median(launch_ms)) * 1e-3
@@ -260,6 +283,8 @@ def main():
                         "frac": f_alg * B / launch_s / 1e12 / 78.6}
         if cadence is not None:
             out["cadence_250_30"] = cadence
+        if single is not None:
+            out["single_filter_n12"] = single
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["parity_max_rel_err"] = parity
