@@ -192,6 +192,30 @@ int update_entry(viekf_seq* s, SeqMeas& m, std::vector<int32_t>& res) {   // VIE
   return rc;
 }
 
+// entries of one camera frame: unhandled active FEAT measurements with the same time stamp and the same R
+bool frame_mate(const SeqMeas& a, const SeqMeas& z) {
+  return !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim && a.R == z.R;
+}
+
+// the k entries zbuf[zi], zbuf[zi-1], ..., zbuf[zi-k+1] (the order handle_measurements visits them) as one launch;
+// res [B][k]
+int update_frame(viekf_seq* s, long zi, int k, std::vector<int32_t>& res) {
+  const int B = s->B;
+  std::vector<double> z((size_t)B * k * 2);
+  std::vector<int32_t> slot((size_t)B * k, -1);
+  for (int j = 0; j < k; j++) {
+    SeqMeas& m = s->zbuf[zi - j];
+    m.handled = true;                                              // :198
+    for (int b = 0; b < B; b++) {
+      z[((size_t)b * k + j) * 2] = m.z[(size_t)b * 2];
+      z[((size_t)b * k + j) * 2 + 1] = m.z[(size_t)b * 2 + 1];
+      slot[(size_t)b * k + j] = m.present[b] ? local_id(s, b, m.id[b]) : -1;
+    }
+  }
+  res.assign((size_t)B * k, VIEKF_MEAS_SKIPPED);
+  return viekf_batch_update_feat(s->core, z.data(), slot.data(), k, s->zbuf[zi].R.data(), 0, res.data(), VIEKF_HOST);
+}
+
 }  // namespace
 
 extern "C" {
@@ -317,10 +341,27 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
       if (s->t[s->i] < z.t)                                        // :81-82
         if (int rc = propagate_core(s, s->u[ui].second.data(), z.t, false)) return rc;
       if (!z.handled) {                                            // :87-95
-        if (int rc = update_entry(s, z, res)) return rc;
-        if (z.type == VIEKF_FEAT)
-          for (int b = 0; b < B; b++)
-            if (res[b] == VIEKF_MEAS_GATED) gated[b].push_back(z.id[b]);
+        // A camera frame queues one FEAT entry per feature, all with the same time stamp: the reference applies them one
+        // after the other with nothing in between (no propagate: :81 is false, :100 does not fire), so they go to the device
+        // as ONE launch of M sequential updates -- the same arithmetic, P crosses HBM once per frame instead of once per
+        // feature.  (Not while logging: the log wants zhat before every single update.)
+        long zl = zi;
+        if (s->log.empty() && z.type == VIEKF_FEAT && z.active)
+          while (zl > 0 && frame_mate(s->zbuf[zl - 1], z)) zl--;
+        if (zl < zi) {
+          const int k = (int)(zi - zl + 1);
+          std::vector<int32_t> resk;
+          if (int rc = update_frame(s, zi, k, resk)) return rc;
+          for (int j = 0; j < k; j++)
+            for (int b = 0; b < B; b++)
+              if (resk[(size_t)b * k + j] == VIEKF_MEAS_GATED) gated[b].push_back(s->zbuf[zi - j].id[b]);
+          zi = zl;                                                 // (the bookkeeping below continues from the frame's last entry)
+        } else {
+          if (int rc = update_entry(s, z, res)) return rc;
+          if (z.type == VIEKF_FEAT)
+            for (int b = 0; b < B; b++)
+              if (res[b] == VIEKF_MEAS_GATED) gated[b].push_back(z.id[b]);
+        }
       }
       if (zi != 0) {                                               // :97-105
         zi--;
