@@ -263,7 +263,7 @@ def test_device_pointer_path_matches_host_path():
     assert np.array_equal(g1.get_covariance(), g2.get_covariance())
 
 
-@pytest.mark.parametrize("N,M", [(64, 4), (150, 3), (51, 51), (150, 40), (160, 35)])
+@pytest.mark.parametrize("N,M", [(64, 4), (150, 3), (51, 51), (150, 40), (160, 35), (160, 160)])
 def test_wide_p_streaming_family(N, M):
     """wide covariance (BASELINE config 5: N=150, n=466): the streaming family -- a few updates per step, and enough of them
     for full 16-measurement groups plus a partial one (N=160 is the ABI limit: whole 48-row super-tiles in the propagate,
