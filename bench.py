@@ -206,6 +206,23 @@ def main():
         tc = time.perf_counter() - tc
         cadence = {"imu_steps_per_s": B * 25 * cyc / tc, "frames_per_s": B * 3 * cyc / tc,
                    "what": "25 propagates : 3 frames of %d feature updates, %d cycles" % (N, cyc)}
+        # the same work with the IMU samples between two frames fused into the frame's launch (viekf_batch_step_n, K = 8, 8, 9)
+        try:
+            ks = (8, 8, 9)
+            uu = [torch.stack([d_u[(j + 3 * q) % uniq] for j in range(k)]).contiguous() for q, k in enumerate(ks)]
+            dd = [torch.stack([d_dt for _ in range(k)]).contiguous() for k in ks]
+            g.step_n(uu[0], dd[0], d_z[0], d_slot, d_R, result=d_res)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for c in range(cyc):
+                for q in range(3):
+                    g.step_n(uu[q], dd[q], d_z[q % uniq], d_slot, d_R, result=d_res)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf
+            cadence["fused_imu_steps_per_s"] = B * 25 * cyc / tf
+            cadence["fused_what"] = "3 launches of K = 8, 8, 9 propagates + %d updates (viekf_batch_step_n)" % N
+        except Exception as e:
+            cadence["fused_error"] = str(e)[:200]
 
     # ... and the reference's own CPU-runnable case (BASELINE configs[0]): ONE filter, N_feat = 12, step latency
     single = None

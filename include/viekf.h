@@ -196,6 +196,11 @@ int viekf_batch_update(viekf_batch *b, int32_t type, const double *z, int32_t zd
 /* one hot-path step = propagate + M feature updates, fused where the kernel family allows */
 int viekf_batch_step(viekf_batch *b, const double *u, const double *dt, const double *z, const int32_t *slot,
                      int32_t M, const double *R, int32_t r_mode, int32_t *result, viekf_mem where);
+/* The same with K IMU samples in front of the frame's updates (250 Hz IMU, 30 Hz camera: K = 8 or 9): K x propagate_state,
+ * then the M updates, in ONE launch of the fused kernel -- P stays on chip in between, bit for bit what K - 1 calls of
+ * viekf_batch_propagate followed by viekf_batch_step give.  u [K][batch][6], dt [K][batch]; 1 <= K <= 64; M may be 0. */
+int viekf_batch_step_n(viekf_batch *b, int32_t K, const double *u, const double *dt, const double *z, const int32_t *slot,
+                       int32_t M, const double *R, int32_t r_mode, int32_t *result, viekf_mem where);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Host sequencer on top of a batch whose filters share ONE clock (same IMU / measurement timestamps, different data):

@@ -140,3 +140,40 @@ def test_propagate_to_ring_slot_equals_in_place(N, kernel):
     assert np.array_equal(ga.get_covariance(), gb.get_covariance())
     gb.history_resize(0)                            # leaving the ring brings the live state home
     assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4)])
+def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
+    """viekf_batch_step_n: K IMU samples and the frame's updates in one launch (P stays on chip in the fused kernel) --
+    bit for bit the K - 1 propagate calls + one step they replace; a forced negative depth makes a propagate's fix_depth
+    edit P(rho,rho) in the middle of the sequence"""
+    import vi_ekf_amd as v
+    from vi_ekf_amd import scene
+    B = 300 if N == 20 else 3        # (N = 20 with a batch above the CU count: the two-per-CU instance)
+    sc = scene.make_scene(B, N, K, seed=17 + N)
+    gs = []
+    for _ in range(2):
+        g = v.BatchVIEKF(B, N, sc["params"])
+        g.set_kernel(kernel)
+        for i in range(N):
+            g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        x = g.get_state()
+        x[0, 17 + 4] = -0.2           # rho < 0: fixed (and flagged) by the first propagate
+        x[1 % B, 17 + 5 + 4] = 300.0  # rho > 100: reset by the first propagate
+        g.set_state(x=x)
+        gs.append(g)
+    dt = np.tile(sc["dt"], (K, 1)) * np.linspace(0.8, 1.2, K)[:, None]
+    ra = gs[0].step_n(sc["u"][:K], dt, sc["z"][0], sc["slot"], sc["R"])
+    for k in range(K - 1):
+        gs[1].propagate(sc["u"][k], dt[k])
+    rb = gs[1].step(sc["u"][K - 1], dt[K - 1], sc["z"][0], sc["slot"], sc["R"])
+    assert (ra == rb).all()
+    assert np.array_equal(gs[0].get_state(), gs[1].get_state())
+    assert np.array_equal(gs[0].get_covariance(), gs[1].get_covariance())
+    assert (gs[0].get_status() == gs[1].get_status()).all() and (gs[0].get_status()[0] & 4)
+    # K propagates without measurements
+    gs[0].step_n(sc["u"][:K], dt, None, None, sc["R"])
+    for k in range(K):
+        gs[1].propagate(sc["u"][k], dt[k])
+    assert np.array_equal(gs[0].get_covariance(), gs[1].get_covariance())

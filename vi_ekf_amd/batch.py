@@ -263,6 +263,22 @@ class BatchVIEKF:
     def restore(self, slot):
         capi.check(capi.lib().viekf_batch_restore(self._h, int(slot)))
 
+    def step_n(self, u, dt, z, slot, R, result=None):
+        """K propagates (u [K,B,6], dt [K,B]: the IMU samples since the last frame) + M feature updates in one launch"""
+        self._keep = []
+        K = int(u.shape[0])
+        pu, w0 = self._arg(u, np.float64, (K, self.B, 6), None)
+        pdt, w0 = self._arg(dt, np.float64, (K, self.B), w0)
+        if z is None:     # K propagates, no measurements
+            M, pz, ps, pR, r_mode, pres, result, w = 0, None, None, None, 0, None, None, w0
+        else:
+            M, pz, ps, pR, r_mode, pres, result, w = self._meas_args(z, slot, R, result)
+        if w != w0:
+            raise ValueError("cannot mix host and device arguments in one call")
+        capi.check(capi.lib().viekf_batch_step_n(self._h, K, pu, pdt, pz, ps, M, pR, r_mode, pres, w))
+        self._keep = []
+        return result
+
     def step(self, u, dt, z, slot, R, result=None):
         """one hot-path step: propagate + M feature updates"""
         self._keep = []

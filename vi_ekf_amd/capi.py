@@ -26,7 +26,7 @@ SYMBOLS = [
     "viekf_seq_create", "viekf_seq_destroy", "viekf_seq_propagate", "viekf_seq_add_measurement",
     "viekf_seq_handle_measurements", "viekf_seq_keep_only_features", "viekf_seq_tracked_features", "viekf_seq_status",
     "viekf_batch_eval_xdot", "viekf_batch_eval_h", "viekf_batch_get_cov_diag", "viekf_seq_init_logger",
-    "viekf_seq_disable_logger",
+    "viekf_seq_disable_logger", "viekf_batch_step_n",
 ]
 
 
@@ -130,6 +130,7 @@ def lib():
         L.viekf_batch_snapshot.argtypes = [_vp, C.c_int32]
         L.viekf_batch_restore.argtypes = [_vp, C.c_int32]
         L.viekf_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int]
+        L.viekf_batch_step_n.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp, C.c_int]
         _lib = L
     return _lib
 

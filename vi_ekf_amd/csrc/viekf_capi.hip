@@ -177,10 +177,10 @@ const ResInst kResInst[] = {
 
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
                              const double*, long, long, int*);
-res_kernel_t res_kernel(int inst) {
+res_kernel_t res_kernel(int inst, bool multi = false) {   // multi: several propagates per launch (viekf_batch_step_n)
   switch (inst) {
-    case 0: return k_step_resident<3, 2>;
-    case 1: return k_step_resident<3, 7>;
+    case 0: return multi ? k_step_resident<3, 2, true> : k_step_resident<3, 2, false>;
+    case 1: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
   }
   return nullptr;
 }
@@ -205,6 +205,8 @@ int setup_resident(viekf_batch* b) {
     if (L.Pbb - L.X < 4 * b->n) continue;   // the second gain-row buffer lives in the propagate-only scratch starting at X
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
     break;
   }
@@ -223,7 +225,7 @@ bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family !
 // one launch handles at most MCAP measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
-                    double* P_out = nullptr) {
+                    double* P_out = nullptr, int KP = 1) {
   StreamArgs a = make_args(b);
   if (x_out) { a.x_out = x_out; a.P_out = P_out; }   // (only meaningful for a single-chunk launch)
   long rsb = 0, rsm = 0;
@@ -233,8 +235,8 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   int m0 = 0;
   do {
     const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
-    hipLaunchKernelGGL(res_kernel(b->res_inst), dim3(b->B), dim3((r.NW + 1) * 64), b->res_lds, b->stream, a, b->res_TR,
-                       b->res_TC, ((do_prop && m0 == 0) ? 1 : 0) | (dbg_bits() << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
+    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1), dim3(b->B), dim3((r.NW + 1) * 64), b->res_lds, b->stream, a, b->res_TR,
+                       b->res_TC, ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
     HIP_TRY(hipGetLastError());
@@ -565,8 +567,9 @@ int viekf_batch_init_feature(viekf_batch* b, const double* pix, const double* de
 
 static int update_or_step(viekf_batch* b, const double* u, const double* dt, bool with_propagate, const double* z,
                           const int32_t* slot, int32_t M, const double* R, int32_t r_mode, int32_t* result,
-                          viekf_mem where) {
+                          viekf_mem where, int K = 1) {
   if (int rc = check_batch(b)) return rc;
+  if (K < 1 || K > 64) return fail(VIEKF_ERR_INVALID, "1 <= K <= 64 propagates per call");
   if (M < 0) return fail(VIEKF_ERR_INVALID, "M must be >= 0");
   if (r_mode < 0 || r_mode > 2) return fail(VIEKF_ERR_INVALID, "r_mode must be 0, 1 or 2");
   if (M > 0 && (!z || !slot || !R)) return fail(VIEKF_ERR_INVALID, "z, slot and R must not be null when M > 0");
@@ -577,14 +580,14 @@ static int update_or_step(viekf_batch* b, const double* u, const double* dt, boo
   const int32_t* d_slot = nullptr;
   int32_t* d_res = nullptr;
   if (where == VIEKF_HOST) {
-    size_t need = stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B) +
+    size_t need = stage_size(sizeof(double) * 6 * b->B * K) + stage_size(sizeof(double) * b->B * K) +
                   stage_size(sizeof(double) * 2 * BM) + stage_size(sizeof(int32_t) * BM) * 2 +
                   stage_size(sizeof(double) * r_count(b, M, r_mode));
     if (int rc = stage_begin(b, need)) return rc;
   }
   if (with_propagate) {
-    if (int rc = in_ptr(b, u, (size_t)6 * b->B, where, &d_u)) return rc;
-    if (int rc = in_ptr(b, dt, (size_t)b->B, where, &d_dt)) return rc;
+    if (int rc = in_ptr(b, u, (size_t)6 * b->B * K, where, &d_u)) return rc;
+    if (int rc = in_ptr(b, dt, (size_t)b->B * K, where, &d_dt)) return rc;
   }
   if (M > 0) {
     if (int rc = in_ptr(b, z, 2 * BM, where, &d_z)) return rc;
@@ -594,10 +597,11 @@ static int update_or_step(viekf_batch* b, const double* u, const double* dt, boo
   }
   if (use_resident(b)) {
     if (with_propagate || M > 0)
-      if (int rc = launch_resident(b, with_propagate, d_u, d_dt, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
+      if (int rc = launch_resident(b, with_propagate, d_u, d_dt, d_z, d_slot, M, d_R, r_mode, d_res, nullptr, nullptr, K)) return rc;
   } else {
     if (with_propagate)
-      if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
+      for (int k = 0; k < K; k++)
+        if (int rc = launch_propagate(b, d_u + (size_t)6 * b->B * k, d_dt + (size_t)b->B * k)) return rc;
     if (M > 0)
       if (int rc = launch_update(b, d_z, d_slot, M, d_R, r_mode, d_res)) return rc;
   }
@@ -858,6 +862,11 @@ int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot
 int viekf_batch_step(viekf_batch* b, const double* u, const double* dt, const double* z, const int32_t* slot,
                      int32_t M, const double* R, int32_t r_mode, int32_t* result, viekf_mem where) {
   return update_or_step(b, u, dt, true, z, slot, M, R, r_mode, result, where);
+}
+
+int viekf_batch_step_n(viekf_batch* b, int32_t K, const double* u, const double* dt, const double* z, const int32_t* slot,
+                       int32_t M, const double* R, int32_t r_mode, int32_t* result, viekf_mem where) {
+  return update_or_step(b, u, dt, true, z, slot, M, R, r_mode, result, where, K);
 }
 
 }  // extern "C"

@@ -166,7 +166,7 @@ struct ResShared {  // resolved LDS pointers + launch constants shared by both r
   int* mslot;   // [MCAP] slot, or -1 for a measurement that is not run
   int2* mseq;   // [MCAP] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
-  int N, n, nf, len, M, mstride, do_prop, b, dbg;
+  int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B;   // kp: propagates per launch (viekf_batch_step_n)
   double* stamps;
 };
 
@@ -186,8 +186,8 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
   double* Pbc = S.Pbc; double* Pbb = S.Pbb;
   double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
   double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
+    __syncthreads();  // B1p : body Jacobian ready (service), and this propagate's dt
   const double dt = S.sm[42];
-    __syncthreads();  // B1p : body Jacobian ready (service)
 
     for (int e = tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303)
       const int r = e >> 4, c = e & 15;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResSh
   }
 }
 
-template <int RB, int TW>
+template <int RB, int TW, bool MP>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
   double* P = a.P + (long)S.b * n * ld;
@@ -469,9 +469,18 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   __syncthreads();  // B0
   RES_STAMP(S, tid == 0, 65);
 
-  if (S.do_prop) {
+  // K propagates per launch (viekf_batch_step_n: the IMU samples between two camera frames) keep P on chip in between:
+  // bit for bit what K launches would give, without their HBM round trips
+  // (MP = false -- one propagate, every launch but viekf_batch_step_n's -- is a separate instance: the loop costs the
+  //  single-propagate kernel 2 % in registers kept alive across it)
+  const int nkp = MP ? S.kp : 1;
+  if (S.do_prop)
+   for (int kp = 0; kp < nkp; kp++) {
+    // (the thread index is laundered per propagate: otherwise everything derived from it is hoisted out of this loop and
+    //  kept alive across it -- spills)
+    const int tk = MP ? opaque(tid) : tid;
     double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
-    res_prop_setup<TW>(a, S, tid);
+    res_prop_setup<TW>(a, S, tk);
     RES_STAMP(S, tid == 0, 66);
     __syncthreads();  // B3p
     RES_STAMP(S, tid == 0, 67);
@@ -534,12 +543,24 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     sym_diag();
     RES_STAMP(S, tid == 0, 69);
-    res_prop_body<TW>(a, S, tid);
+    res_prop_body<TW>(a, S, tk);
     par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
-    for (int e = tid; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
-  }
+    for (int e = tk; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
+    if (MP && kp + 1 < nkp && td_ == 0 && S.sm[40 + (par ^ 1)] != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
+      const int mb = par ^ 1;
+#pragma unroll
+      for (int ia = 0; ia < RB; ia++) {
+        int I, J;
+        if (blk(tr_, td_, ia, I, J) && I < len) {
+          const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
+          if (ad != 0.0) { pb[ia][8] += ad; S.fixadd[mb * N + I] = 0.0; }
+          if (st != 0.0) { pb[ia][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
+        }
+      }
+    }
+   }
 
   // block indices of this thread, computed once (symmetric ownership left enough registers to keep them)
   int Ib[RB], Jb[RB];
@@ -785,9 +806,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 }
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
-template <int T>
+template <int T, bool MP>
 __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane, int nww,
-                                            const double* __restrict__ u_all, int* __restrict__ result_all) {
+                                            const double* __restrict__ u_all, const double* __restrict__ dt_all,
+                                            int* __restrict__ result_all) {
   const int N = S.N, n = S.n, len = S.len, M = S.M;
   const DevParams& prm = *a.dp;
   double* xs = S.xs;
@@ -800,22 +822,31 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   RES_STAMP(S, lane == 0, 0);
   // The dynamics of the propagate need only the state (in LDS since the prologue): they run BEFORE B0, while the worker
   // waves are still loading P from HBM, instead of holding every worker up afterwards.
-  const double dt = sm[42];
-  if (S.do_prop) {
+  double dt = sm[42];
+  // dynamics of propagate kp (of S.kp): body Jacobian on lane 0, one feature per lane
+  auto dynamics = [&](int kp) {
     for (int i = lane; i < 256; i += 64) S.Abb[i] = 0.0;
     for (int i = lane; i < 96; i += 64) S.Gb[i] = 0.0;
     if (lane < 16) S.xdb[lane] = 0.0;
-    if (lane == 0) res_body_phase(xs, u_all + (long)S.b * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
-    RES_STAMP(S, lane == 0, 2);
+    if (lane == 0) res_body_phase(xs, u_all + ((long)kp * S.B + S.b) * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
+    RES_STAMP(S, lane == 0 && kp == 0, 2);
     // (same wave: the LDS accesses of lane 0 above are complete before the feature lanes read ctx)
     wave_lds_sync();
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, S.featA, S.phiff);
-    RES_STAMP(S, lane == 0, 4);
-  }
+    RES_STAMP(S, lane == 0 && kp == 0, 4);
+  };
+  if (S.do_prop) dynamics(0);
   __syncthreads();  // B0
   RES_STAMP(S, lane == 0, 1);
 
-  if (S.do_prop) {
+  const int nkp = MP ? S.kp : 1;
+  if (S.do_prop)
+   for (int kp = 0; kp < nkp; kp++) {
+    if (MP && kp > 0) {   // (the workers are between B4p and B1p: nothing of theirs touches the dynamics' scratch or xs)
+      dt = dt_all[(long)kp * S.B + S.b];
+      if (lane == 0) sm[42] = dt;
+      dynamics(kp);
+    }
     __syncthreads();  // B1p
     RES_STAMP(S, lane == 0, 3);
     __syncthreads();  // B2p
@@ -838,7 +869,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     RES_STAMP(S, lane == 0, 7);
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
-  }
+   }
 
   // lane roles for the state correction (one instruction stream, no divergence):
   //   lane f < N           : feature f  -> rows 16+3f..+2 : bearing quaternion (2 rows) + inverse depth (1 row)
@@ -1122,7 +1153,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
-  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = do_prop >> 8; S.b = b; S.stamps = a.ws;
+  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
   {
     const double* xg = a.x + (long)b * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
@@ -1154,7 +1185,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   RES_STAMP(S, tid == 0, 63);
 }
 
-template <int RB, int NW>
+template <int RB, int NW, bool MP = false>
 __global__ __launch_bounds__((NW + 1) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
@@ -1173,8 +1204,8 @@ __global__ __launch_bounds__((NW + 1) * 64, (NW <= 3) ? 2 : 1) void k_step_resid
   // the service wave.  With 8 waves (NW = 7) every SIMD holds two and the last wave serves.
   constexpr int SVC = (NW == 6) ? 3 : NW;
   const int wave = tid >> 6;
-  if (wave == SVC) res_service<T>(a, S, tid & 63, NW, u_all, result_all);
-  else res_worker<RB, TW>(a, S, TR, TD, tid - (wave > SVC ? 64 : 0));
+  if (wave == SVC) res_service<T, MP>(a, S, tid & 63, NW, u_all, dt_all, result_all);
+  else res_worker<RB, TW, MP>(a, S, TR, TD, tid - (wave > SVC ? 64 : 0));
 }
 
 }  // namespace viekf
