@@ -824,7 +824,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // waves are still loading P from HBM, instead of holding every worker up afterwards.
   double dt = sm[42];
   // dynamics of propagate kp (of S.kp): body Jacobian on lane 0, one feature per lane
-  auto dynamics = [&](int kp) {
+  auto dynamics = [&](int kp, double dtk, double* phiff_dst) {
     for (int i = lane; i < 256; i += 64) S.Abb[i] = 0.0;
     for (int i = lane; i < 96; i += 64) S.Gb[i] = 0.0;
     if (lane < 16) S.xdb[lane] = 0.0;
@@ -832,21 +832,16 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     RES_STAMP(S, lane == 0 && kp == 0, 2);
     // (same wave: the LDS accesses of lane 0 above are complete before the feature lanes read ctx)
     wave_lds_sync();
-    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dt, xs, S.ctx, S.featA, S.phiff);
+    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dtk, xs, S.ctx, S.featA, phiff_dst);
     RES_STAMP(S, lane == 0 && kp == 0, 4);
   };
-  if (S.do_prop) dynamics(0);
+  if (S.do_prop) dynamics(0, dt, S.phiff);
   __syncthreads();  // B0
   RES_STAMP(S, lane == 0, 1);
 
   const int nkp = MP ? S.kp : 1;
   if (S.do_prop)
    for (int kp = 0; kp < nkp; kp++) {
-    if (MP && kp > 0) {   // (the workers are between B4p and B1p: nothing of theirs touches the dynamics' scratch or xs)
-      dt = dt_all[(long)kp * S.B + S.b];
-      if (lane == 0) sm[42] = dt;
-      dynamics(kp);
-    }
     __syncthreads();  // B1p
     RES_STAMP(S, lane == 0, 3);
     __syncthreads();  // B2p
@@ -867,8 +862,22 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     RES_STAMP(S, lane == 0, 6);
     __syncthreads();  // B3p
     RES_STAMP(S, lane == 0, 7);
+    // Several propagates per launch: the NEXT one's dynamics run here, under the workers' contraction (this wave would
+    // only wait for B4p).  The state they need is final (body step and fix_depth above); of their outputs the workers still
+    // read Phi_ff (local transforms) -- the new blocks go to the idle gain-row buffer and are copied over after B4p --,
+    // nothing else (featA, A_bb, G_b were consumed before B3p; dt is read after B1p).
+    double dt_next = 0.0;
+    if (MP && kp + 1 < nkp) {
+      dt_next = dt_all[(long)(kp + 1) * S.B + S.b];
+      dynamics(kp + 1, dt_next, S.Kt);
+    }
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
+    if (MP && kp + 1 < nkp) {
+      for (int i = lane; i < 9 * N; i += 64) S.phiff[i] = S.Kt[i];
+      dt = dt_next;
+      if (lane == 0) sm[42] = dt;
+    }
    }
 
   // lane roles for the state correction (one instruction stream, no divergence):
