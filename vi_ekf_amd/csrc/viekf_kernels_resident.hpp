@@ -543,7 +543,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     sym_diag();
     RES_STAMP(S, tid == 0, 69);
-    res_prop_body<TW>(a, S, tk);
+    if (MP) res_prop_body<TW>(a, S, tk);   // (single propagate: the service wave does this meanwhile, it would only wait)
     par ^= 1;   // the service wave posted propagate's fix_depth edits into mailbox 0
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
@@ -871,6 +871,9 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       dt_next = dt_all[(long)(kp + 1) * S.B + S.b];
       dynamics(kp + 1, dt_next, S.Kt);
     }
+    // One propagate per launch: this wave takes the body strips and the body block of P+ (res_prop_body: they need U, ready
+    // since B3p, and write what no contraction reads) off the workers' path instead of waiting for them.
+    if (!MP) res_prop_body<64>(a, S, lane);
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
     if (MP && kp + 1 < nkp) {
