@@ -60,8 +60,12 @@ __device__ RES_INLINE void res_body_phase(const double* xs, const double* u, con
   double ub[6];
   q_rota(p->q_b_u, u, ub);
   q_rota(p->q_b_u, u + 3, ub + 3);
-  body_ctx(xs, ub, *p, *ctx);
-  body_dynamics<false>(*ctx, *p, xdb, Abb, Gb);   // the service wave cleared xdb / Abb / Gb cooperatively
+  // (the context is built in registers and handed to LDS once: worked on in place, every store to A / G -- which may alias
+  //  it as far as the compiler knows -- forces the fields to be re-read from LDS, 10 k clk of single-lane latency)
+  BodyCtx c;
+  body_ctx(xs, ub, *p, c);
+  body_dynamics<false>(c, *p, xdb, Abb, Gb);   // the service wave cleared xdb / Abb / Gb cooperatively
+  *ctx = c;
 }
 
 // one feature's share of the propagate set-up on the SERVICE wave: dynamics, Phi_ff, state step.  The 3x16 rows of Phi_fb
