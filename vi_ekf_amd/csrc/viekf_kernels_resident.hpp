@@ -77,16 +77,18 @@ __device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* 
   double* fa = featA + FEATA * f;
   if (f < len) {
     double xd3[3], Afv[9], Afg[9], Aff[9];
-    const double* qz = xs + xZ + 5 * f;
-    const double rho = qz[4];
-    feature_dynamics(qz, rho, *ctx, xd3, Afv, Afg, Aff);
+    const double qz[4] = {xs[xZ + 5 * f], xs[xZ + 5 * f + 1], xs[xZ + 5 * f + 2], xs[xZ + 5 * f + 3]};
+    const double rho = xs[xZ + 5 * f + 4];
+    const BodyCtx c = *ctx;   // (a register copy: the stores below may alias the LDS one as far as the compiler knows)
+    feature_dynamics(qz, rho, c, xd3, Afv, Afg, Aff);
     double Aff2[9], Mff[9], Gff[9];
     mm<3, 3, 3>(Aff, Aff, Aff2);
 #pragma unroll
     for (int e = 0; e < 9; e++) {
       const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
-      Mff[e] = id + Aff[e] * dt / 2.0 + Aff2[e] * dt * dt / 6.0;
-      phiff[9 * f + e] = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
+      // (dt^2/6 as one factor: a true division per element is ~15 dependent instructions; 1 ulp from the reference's order)
+      Mff[e] = id + Aff[e] * (0.5 * dt) + Aff2[e] * (dt * dt * (1.0 / 6.0));
+      phiff[9 * f + e] = id + Aff[e] * dt + Aff2[e] * (0.5 * dt * dt);
     }
     mm<3, 3, 3>(Mff, Afg, Gff);
 #pragma unroll
@@ -199,8 +201,8 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
 #pragma unroll 4
       for (int k = 0; k < 16; k++) a2 += S.Abb[r * 16 + k] * S.Abb[k * 16 + c];
       const double id = (r == c) ? 1.0 : 0.0, av = S.Abb[e];
-      Mbb[e] = id + av * dt / 2.0 + a2 * dt * dt / 6.0;
-      const double ph = id + av * dt + a2 * dt * dt / 2.0;
+      Mbb[e] = id + av * (0.5 * dt) + a2 * (dt * dt * (1.0 / 6.0));
+      const double ph = id + av * dt + a2 * (0.5 * dt * dt);
       Phibb[e] = ph;
       S.PhibbT[c * 16 + r] = ph;   // transposed copy: lanes that differ in the OUTPUT column read consecutive words
     }
@@ -224,7 +226,7 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
 #pragma unroll
         for (int k = 0; k < 3; k++) a2 += fa[18 + r * 3 + k] * blk3[k * 3 + cc];
       }
-      const double ph = afb * dt + a2 * dt * dt / 2.0;
+      const double ph = afb * dt + a2 * (0.5 * dt * dt);
       X[row * XK + 16 + c] = ph;
       Y[row * XK + c] = ph;
     }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
 #pragma unroll
               for (int j = 0; j < 3; j++)
                 ga += fa[r * 3 + j] * S.Gb[(dxVEL + j) * 6 + lr] + fa[9 + r * 3 + j] * S.Gb[(dxB_G + j) * 6 + lr];
-              double g = accG[r4] / 3.0 + ga * dt / 6.0;
+              double g = accG[r4] * (1.0 / 3.0) + ga * (dt * (1.0 / 6.0));
               if (lr >= 3) g += fa[27 + r * 3 + (lr - 3)];
               g *= dt;
               Y[row * XK + 32 + lr] = g;
