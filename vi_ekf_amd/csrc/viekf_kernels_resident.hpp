@@ -308,38 +308,64 @@ __device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShar
     // per wave and turn, 6 k-steps (the last two hold the 6 input-noise columns, zero padded)
     {
       const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
-      for (int t = wv; t * 16 < nf; t += TW / 64) {
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* xr = X + min(16 * t + lr, nf - 1) * XK;
+      constexpr int step = TW / 64;
+      // the right-hand operands do not depend on the tile: loaded once; two tiles per turn, so that one tile's dependent
+      // MFMA chain runs in the shadow of the other's
+      double bph[4], bgd[2];
 #pragma unroll
-        for (int sk = 0; sk < 4; sk++) {
-          const int c = 4 * sk + lk;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[c], S.PhibbT[c * 16 + lr], acc, 0, 0, 0);
-        }
+      for (int sk = 0; sk < 4; sk++) bph[sk] = S.PhibbT[(4 * sk + lk) * 16 + lr];
+#pragma unroll
+      for (int sk = 0; sk < 2; sk++) { const int c = 4 * sk + lk; bgd[sk] = (c < 6) ? Gdb[lr * 6 + c] : 0.0; }   // (c = 0..7, noise columns c < 6)
+      for (int t = wv; t * 16 < nf; t += 2 * step) {
+        const int t1 = t + step;
+        const double* xr0 = X + min(16 * t + lr, nf - 1) * XK;
+        const double* xr1 = X + min(16 * t1 + lr, nf - 1) * XK;
+        double a0[6], a1[6];
+#pragma unroll
+        for (int sk = 0; sk < 4; sk++) { a0[sk] = xr0[4 * sk + lk]; a1[sk] = xr1[4 * sk + lk]; }
 #pragma unroll
         for (int sk = 0; sk < 2; sk++) {
-          const int c = 4 * sk + lk;                       // 0..7, the input-noise columns are c < 6
-          const double av = (c < 6) ? xr[32 + c] : 0.0;
-          const double bv = (c < 6) ? Gdb[lr * 6 + c] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          const int c = 4 * sk + lk;
+          a0[4 + sk] = (c < 6) ? xr0[32 + c] : 0.0;
+          a1[4 + sk] = (c < 6) ? xr1[32 + c] : 0.0;
+        }
+        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sk = 0; sk < 6; sk++) {
+          const double bv = sk < 4 ? bph[sk] : bgd[sk - 4];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sk], bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sk], bv, acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
-          const int row = 16 * t + lk + 4 * r4;
-          if (row < nf) Pbc[row * 16 + lr] = acc[r4];
+          const int row0 = 16 * t + lk + 4 * r4, row1 = 16 * t1 + lk + 4 * r4;
+          if (row0 < nf) Pbc[row0 * 16 + lr] = acc0[r4];
+          if (row1 < nf) Pbc[row1 * 16 + lr] = acc1[r4];
         }
       }
     }
-    for (int e = tid; e < 256; e += TW) {
-      const int r = e >> 4, c = e & 15;
-      double s = 0.0;
-#pragma unroll 4
-      for (int k = 0; k < 16; k++) s += T16[r * 16 + k] * S.PhibbT[k * 16 + c];   // (Phi_bb[c][k]: the transposed copy is conflict-free)
-      double g = 0.0;
-      for (int k = 0; k < 6; k++) g += Gdb[r * 6 + k] * prm.Qu[k] * Gdb[c * 6 + k];
-      s = s + g;
-      if (r == c) s += a.Qx[r];
-      S.Mbb[e] = s;   // P_bb+ staged in Mbb (T16 / Pbb are still being read by other threads)
+    // body block  P_bb+ = T16 Phi_bb^T + (Gd_b Qu) Gd_b^T + Qx : one 16 x 16 tile, 4 + 2 k-steps, on the first wave
+    // (as 256 x 22-term dot products it was the longest item of this function)
+    if (tid < 64) {
+      const int lr = tid & 15, lk = tid >> 4;
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sk = 0; sk < 4; sk++) {
+        const int k = 4 * sk + lk;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T16[lr * 16 + k], S.PhibbT[k * 16 + lr], acc, 0, 0, 0);   // rows r = lr | cols c = lr
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; sk++) {
+        const int k = 4 * sk + lk;                                   // 0..7, the input-noise columns are k < 6
+        const double av = (k < 6) ? Gdb[lr * 6 + k] * prm.Qu[k] : 0.0;
+        const double bv = (k < 6) ? Gdb[lr * 6 + k] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int r = lk + 4 * r4, c = lr;                           // a result lane holds column lr of rows lk + 4 r4
+        S.Mbb[r * 16 + c] = acc[r4] + ((r == c) ? a.Qx[r] : 0.0);    // P_bb+ staged in Mbb (T16 / Pbb are still being read)
+      }
     }
 }
 
