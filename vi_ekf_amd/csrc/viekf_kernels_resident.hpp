@@ -210,6 +210,13 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
 
     // Phi_fb rows (vi_ekf.cpp:302-303 restricted to the feature/body block): one (feature row, body column) per item
     //   A_fb = [.. Afv(VEL) .. Afg(B_G) ..],  (A^2)_fb = A_fb A_bb + A_ff A_fb
+    // (a thread's items all have the same body column c -- TW is a multiple of 16 --: its six A_bb entries are read once)
+    double abv[3], abg[3];
+    {
+      const int c = tid & 15;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { abv[k] = S.Abb[(dxVEL + k) * 16 + c]; abg[k] = S.Abb[(dxB_G + k) * 16 + c]; }
+    }
 #pragma unroll 1
     for (int e = tid; e < nf * 16; e += TW) {
       const int row = e >> 4, c = e & 15, f = row / 3, r = row - 3 * f;
@@ -220,8 +227,7 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
       const double afb = (cv || cg) ? blk3[r * 3 + cc] : 0.0;
       double a2 = 0.0;
 #pragma unroll
-      for (int k = 0; k < 3; k++)
-        a2 += fa[r * 3 + k] * S.Abb[(dxVEL + k) * 16 + c] + fa[9 + r * 3 + k] * S.Abb[(dxB_G + k) * 16 + c];
+      for (int k = 0; k < 3; k++) a2 += fa[r * 3 + k] * abv[k] + fa[9 + r * 3 + k] * abg[k];
       if (cv || cg) {
 #pragma unroll
         for (int k = 0; k < 3; k++) a2 += fa[18 + r * 3 + k] * blk3[k * 3 + cc];
