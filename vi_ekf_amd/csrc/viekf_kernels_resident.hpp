@@ -247,17 +247,27 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
     // A result lane holds column lr = lane & 15 of rows lk + 4 r (lk = lane >> 4) of the tile.
     {
       const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+      // (everything that does not depend on the tile is read once: the compiler cannot hoist it itself, the stores to X / Y
+      //  below may alias it as far as it knows)
+      const int lq = min(lr, 5);
+      double bgv[4], buv[4], gbv[3], gbg[3];
+#pragma unroll
+      for (int sk = 0; sk < 4; sk++) {
+        const int c = 4 * sk + lk;
+        bgv[sk] = (lr < 6) ? S.Gb[c * 6 + lq] : 0.0;
+        buv[sk] = Pbb[c * 16 + lr];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) { gbv[j] = S.Gb[(dxVEL + j) * 6 + lq]; gbg[j] = S.Gb[(dxB_G + j) * 6 + lq]; }
+      const double quv = prm.Qu[lq], dt6 = dt * (1.0 / 6.0);
       for (int t = wv; t * 16 < nf; t += TW / 64) {
         v4f64 accG = {0.0, 0.0, 0.0, 0.0}, accU = {0.0, 0.0, 0.0, 0.0};
         const double* arow = Y + min(16 * t + lr, nf - 1) * XK;
 #pragma unroll
         for (int sk = 0; sk < 4; sk++) {
-          const int c = 4 * sk + lk;
-          const double av = arow[c];
-          const double bg = (lr < 6) ? S.Gb[c * 6 + lr] : 0.0;
-          const double bu = Pbb[c * 16 + lr];
-          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bg, accG, 0, 0, 0);
-          accU = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bu, accU, 0, 0, 0);
+          const double av = arow[4 * sk + lk];
+          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bgv[sk], accG, 0, 0, 0);
+          accU = __builtin_amdgcn_mfma_f64_16x16x4f64(av, buv[sk], accU, 0, 0, 0);
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
@@ -268,13 +278,12 @@ __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResSha
             if (lr < 6) {
               double ga = 0.0;
 #pragma unroll
-              for (int j = 0; j < 3; j++)
-                ga += fa[r * 3 + j] * S.Gb[(dxVEL + j) * 6 + lr] + fa[9 + r * 3 + j] * S.Gb[(dxB_G + j) * 6 + lr];
-              double g = accG[r4] * (1.0 / 3.0) + ga * (dt * (1.0 / 6.0));
+              for (int j = 0; j < 3; j++) ga += fa[r * 3 + j] * gbv[j] + fa[9 + r * 3 + j] * gbg[j];
+              double g = accG[r4] * (1.0 / 3.0) + ga * dt6;
               if (lr >= 3) g += fa[27 + r * 3 + (lr - 3)];
               g *= dt;
               Y[row * XK + 32 + lr] = g;
-              X[row * XK + 32 + lr] = g * prm.Qu[lr];
+              X[row * XK + 32 + lr] = g * quv;
             }
             double sv = 0.0;
 #pragma unroll
