@@ -48,28 +48,56 @@ def reduce_times(local_seconds, world):
     return float(t.item())
 
 
-def cpu_baseline_and_parity(sc, N, params, gpu_x, gpu_P, steps_cmp, n_filters, threads):
-    """Time the oracle on `n_filters` filters x `steps_cmp` steps of the SAME inputs and compare
-    with the GPU state after the same steps.  Checker/baseline only -- never the product path."""
+def reduce_record(steps, seconds, nbytes, max_rel_err, world):
+    """the one collective of the run -- every rank's {steps, seconds, bytes, max_rel_err} reduced to
+    {sum, max, sum, max} (two all_reduce calls of two doubles each over RCCL / gloo)."""
+    if world == 1:
+        return {"steps": float(steps), "seconds": float(seconds), "bytes": float(nbytes), "max_rel_err": float(max_rel_err)}
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    tot = torch.tensor([float(steps), float(nbytes)], dtype=torch.float64, device=dev)
+    mx = torch.tensor([float(seconds), float(max_rel_err)], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return {"steps": float(tot[0].item()), "seconds": float(mx[0].item()), "bytes": float(tot[1].item()),
+            "max_rel_err": float(mx[1].item())}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_run(sc, N, params, which, steps_cmp, threads, structured=False):
+    """The oracle on filters `which` x `steps_cmp` steps of the SAME inputs -> (x, P, seconds).
+    Checker / baseline only -- never the product path."""
     from oracle import oracle as orc
     keys = ("x0", "P0", "Qx", "lam", "Qu", "P0_feat", "Qx_feat", "lam_feat", "cam_center", "focal_len", "q_b_c",
             "p_b_c", "q_b_u", "min_depth", "use_drag_term", "use_partial_update", "use_keyframe_reset")
     fs = []
-    for b in range(n_filters):
+    for b in which:
         f = orc.OracleFilter(N).init(**{k: params[k] for k in keys})
         for i in range(N):
             f.init_feature(sc["pix"][b, i], i)
         fs.append(f)
-    u = np.ascontiguousarray(sc["u"][:steps_cmp, :n_filters].transpose(1, 0, 2))
-    z = np.ascontiguousarray(sc["z"][:steps_cmp, :n_filters].transpose(1, 0, 2, 3))
+    u = np.ascontiguousarray(sc["u"][:steps_cmp, which].transpose(1, 0, 2))
+    z = np.ascontiguousarray(sc["z"][:steps_cmp, which].transpose(1, 0, 2, 3))
     t0 = time.perf_counter()
-    orc.run_steps_mt(fs, threads, u, float(sc["dt"][0]), z, sc["slot"][:n_filters], sc["R"])
+    orc.run_steps_mt(fs, threads, u, float(sc["dt"][0]), z, sc["slot"][which], sc["R"], structured=structured)
     secs = time.perf_counter() - t0
-    xr = np.stack([f.x for f in fs])
-    Pr = np.stack([f.P for f in fs])
-    ex = float(np.abs(gpu_x[:n_filters] - xr).max() / np.abs(xr).max())
-    eP = float(np.abs(gpu_P[:n_filters] - Pr).max() / np.abs(Pr).max())
-    return n_filters * steps_cmp / secs, secs, max(ex, eP)
+    return np.stack([f.x for f in fs]), np.stack([f.P for f in fs]), secs
+
+
+def rel_err(gpu_x, gpu_P, xr, Pr):
+    ex = float(np.abs(gpu_x - xr).max() / np.abs(xr).max())
+    eP = float(np.abs(gpu_P - Pr).max() / np.abs(Pr).max())
+    return max(ex, eP)
 
 
 def main():
@@ -131,6 +159,7 @@ def main():
     d_slot = torch.tensor(sc["slot"], device=dev)
     d_R = torch.tensor(sc["R"], device=dev)
     d_res = torch.empty((B, N), dtype=torch.int32, device=dev)
+    d_res_all = torch.zeros((K, B, N), dtype=torch.int32, device=dev)   # result codes of every timed update
     d_pix = torch.tensor(np.ascontiguousarray(sc["pix"].transpose(1, 0, 2)), device=dev)  # [N][B][2]
     d_nan = torch.full((B,), float("nan"), dtype=torch.float64, device=dev)
 
@@ -139,32 +168,53 @@ def main():
         for i in range(N):
             g.init_feature(d_pix[i], d_nan)
 
-    def step(s):
-        g.step(d_u[s % uniq], d_dt, d_z[s % uniq], d_slot, d_R, result=d_res)
+    def step(s, res=None):
+        g.step(d_u[s % uniq], d_dt, d_z[s % uniq], d_slot, d_R, result=d_res if res is None else res)
 
-    # ---- phase A (rank 0, N=1 run only): parity vs the oracle + CPU baseline on a bounded sample
+    # ---- phase A: parity vs the oracle on a STRIDED sample of this rank's filters (first / last / every dispatch round),
+    #      and -- rank 0 of the N=1 run only -- the CPU baselines on a bounded sample of the same workload
     cpu = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(os.cpu_count() or 1, 16)
-        nf = args.cpu_filters or min(B, 8 * threads)
-        # keep the sample at ~10-30 s of CPU work: dense cost ~ (8 + 4N) n^3 flop per filter-step,
-        # assuming ~6 GFLOP/s per thread for the plain-C dense loops; capped by the distinct frames
+    parity = 0.0
+    if not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
         n = 16 + 3 * N
-        flop = (8 + 4 * N) * float(n) ** 3
-        sc_steps = args.cpu_steps or int(max(1, min(uniq, round(15.0 * 6.0e9 * threads / (flop * nf)))))
+        flop = (8 + 4 * N) * float(n) ** 3      # dense cost per filter-step; ~6 GFLOP/s per thread for the plain-C loops
+        if world == 1:
+            threads = min(ncpu, 16)
+            nf = args.cpu_filters or min(B, 8 * threads)
+            # ~10-15 s of CPU work for the all-core dense figure, capped by the distinct frames
+            sc_steps = args.cpu_steps or int(max(1, min(uniq, round(12.0 * 6.0e9 * threads / (flop * nf)))))
+        else:   # N > 1: every rank checks 8 of its own filters, sharing the host cores with the other ranks
+            threads = max(1, min(8, ncpu // world))
+            nf = min(B, 8)
+            sc_steps = int(max(1, min(uniq, 3, round(4.0 * 6.0e9 * threads / (flop * nf)))))
+        which = np.unique(np.linspace(0, B - 1, nf).round().astype(int))   # strided: filters of every dispatch round
         init_filters()
         for s in range(sc_steps):
             step(s)
         torch.cuda.synchronize()
-        gx, gP = g.get_state(), g.get_covariance()
-        rate, secs, err = cpu_baseline_and_parity(sc, N, params, gx, gP, sc_steps, nf, threads)
-        cpu = {"value": rate, "unit": "EKF steps/s", "cores": threads, "kind": "port",
-               "sample": "%d filters x %d steps of the same inputs, dense reference-order oracle, %.1f s wall"
-                         % (nf, sc_steps, secs)}
-        parity = err
-        if err > 1e-6:
-            raise SystemExit("PARITY FAILURE vs oracle: rel err %.3e" % err)
+        gx, gP = g.get_state()[which], g.get_covariance()[which]
+        xr, Pr, secs_d = oracle_run(sc, N, params, which, sc_steps, threads)
+        parity = rel_err(gx, gP, xr, Pr)
+        if parity > 1e-6:
+            raise SystemExit("PARITY FAILURE vs oracle (rank %d): rel err %.3e" % (rank, parity))
+        if rank == 0 and world == 1:
+            cpu = {"value": len(which) * sc_steps / secs_d, "unit": "EKF steps/s", "cores": threads, "kind": "port",
+                   "cpu_model": cpu_model(), "host_cores": ncpu,
+                   "sample": "%d filters (strided over the batch) x %d steps of the same inputs, dense reference-order oracle "
+                             "(vi_ekf.cpp:301-304, vi_ekf_meas.cpp:232-257), %.1f s wall; extrapolates linearly to the batch"
+                             % (len(which), sc_steps, secs_d)}
+            # one-core figure of the same flavour: a few filters, ~3 s
+            n1 = int(max(1, min(len(which), round(3.0 * 6.0e9 / (flop * sc_steps)))))
+            _, _, secs_1 = oracle_run(sc, N, params, which[:n1], sc_steps, 1)
+            cpu["one_core"] = {"value": n1 * sc_steps / secs_1, "sample": "%d filters x %d steps, 1 thread, %.1f s" % (n1, sc_steps, secs_1)}
+            # structured flavour: the block-sparse propagate / rank-2 update the HIP kernels use, on the CPU
+            xs, Ps, secs_s = oracle_run(sc, N, params, which, sc_steps, threads, structured=True)
+            cpu["structured"] = {"value": len(which) * sc_steps / secs_s, "cores": threads,
+                                 "max_rel_err_vs_dense": rel_err(xs, Ps, xr, Pr),
+                                 "sample": "same filters and steps, %.2f s wall" % secs_s}
+            _, _, secs_s1 = oracle_run(sc, N, params, which[:min(len(which), 4)], sc_steps, 1, structured=True)
+            cpu["structured"]["one_core"] = min(len(which), 4) * sc_steps / secs_s1
 
     # ---- phase B: warmup + timed region
     init_filters()
@@ -178,16 +228,26 @@ def main():
     t0 = time.perf_counter()
     ev[0].record()
     for s in range(K):
-        step(W + s)
+        step(W + s, d_res_all[s])
         ev[s + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    secs = reduce_times(secs, world)
+    alg_bytes = scene.algorithmic_bytes_per_step(N) * B  # one launch processes B filter-steps
+    rec = reduce_record(B * K, secs, alg_bytes * K, parity, world)
+    secs = rec["seconds"]
     status = g.get_status()
     n_bad = int((status & 1).sum())
+    # how much work the timed region skipped: a gated / NaN-guarded / invalid update does not run its sweeps
+    codes = d_res_all.view(-1)
+    counts = torch.bincount(codes.clamp(0, 7), minlength=8).cpu().numpy()
+    n_upd = int(codes.numel())
+    work = {"updates": n_upd, "gated_frac": float(counts[1]) / n_upd, "nan_frac": float(counts[2]) / n_upd,
+            "invalid_frac": float(counts[3]) / n_upd,
+            "flag_counts": {"nan": int((status & 1 != 0).sum()), "blowup": int((status & 2 != 0).sum()),
+                            "negative_depth": int((status & 4 != 0).sum()), "internal": int((status & 8 != 0).sum())}}
 
     # ---- secondary numbers, outside the contract's timed region: the realistic cadence 25 IMU propagates :
     #      3 camera frames (250 Hz : 30 Hz, params/sim_params.yaml:149,160) -- 22 propagate-only launches + 3 full steps
@@ -250,7 +310,6 @@ def main():
     # per-launch duration of the step's kernels from HIP events on the launch stream
     launch_ms = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
     launch_s = float(np.median(launch_ms)) * 1e-3
-    alg_bytes = scene.algorithmic_bytes_per_step(N) * B  # one launch processes B filter-steps
     achieved = alg_bytes / launch_s / 1e9
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
@@ -266,10 +325,9 @@ def main():
         traffic = None
 
     if rank == 0:
-        total_filters = B * world
         out = {
             "metric": "EKF steps/sec (IMU-rate propagate + N_feat updates), batch=%d, N_feat=%d" % (B, N),
-            "value": total_filters * K / secs,
+            "value": rec["steps"] / secs,
             "unit": "EKF steps/s",
             "n_gpus": world,
             "steps": K,
@@ -292,6 +350,9 @@ def main():
                                          "median HIP-event duration of the step's launches %.4f ms" % (launch_s * 1e3)),
                          "alg_bytes_per_launch": alg_bytes},
             "nan_filters": n_bad,
+            "gated_frac": work["gated_frac"],
+            "timed_work": work,
+            "reduction": rec,
         }
         # structured algorithmic flops of one step: Phi P Phi^T + G Q G^T + N rank-2 Lambda-masked sweeps
         n_ = 16 + 3 * N
@@ -304,7 +365,8 @@ def main():
             out["single_filter_n12"] = single
         if cpu is not None:
             out["cpu_baseline"] = cpu
-            out["parity_max_rel_err"] = parity
+        if not args.no_cpu_baseline:
+            out["parity_max_rel_err"] = rec["max_rel_err"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -94,6 +94,7 @@ def lib():
         L.vo_run_steps.argtypes = [_fp, C.c_int, _dp, C.c_double, _dp, _ip, C.c_int, _dp, _ip]
         L.vo_run_steps_mt.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.c_int, _dp, C.c_double, _dp, _ip,
                                       C.c_int, _dp, _ip]
+        L.vo_run_steps_mt_flavour.argtypes = L.vo_run_steps_mt.argtypes + [C.c_int]
         for nm, na in (("vo_q_otimes", 3), ("vo_q_exp", 2), ("vo_q_log", 2), ("vo_q_boxplus", 3),
                        ("vo_q_boxminus", 3), ("vo_q_R", 2), ("vo_q_rota", 3), ("vo_q_rotp", 3),
                        ("vo_q_from_two_unit_vectors", 3), ("vo_T_zeta", 2), ("vo_q_feat_boxplus", 3),
@@ -305,8 +306,9 @@ class OracleFilter:
         return res
 
 
-def run_steps_mt(filters, threads, u, dt, z, slot, R):
-    """filters: list[OracleFilter]; u [nf][steps][6]; z [nf][steps][M][2]; slot [nf][M]."""
+def run_steps_mt(filters, threads, u, dt, z, slot, R, structured=False):
+    """filters: list[OracleFilter]; u [nf][steps][6]; z [nf][steps][M][2]; slot [nf][M].
+    structured=True: the block-sparse / rank-2 CPU flavour (second cpu_baseline figure)."""
     L = lib()
     nf = len(filters)
     u = np.ascontiguousarray(u, dtype=np.float64)
@@ -316,6 +318,6 @@ def run_steps_mt(filters, threads, u, dt, z, slot, R):
     Rf = np.ascontiguousarray(np.asarray(R, dtype=np.float64).ravel(order="F"))
     res = np.zeros((nf, steps, M), dtype=np.int32)
     arr = (_fp * nf)(*[f._p for f in filters])
-    L.vo_run_steps_mt(arr, nf, int(threads), steps, _d(u), float(dt), _d(z), slot.ctypes.data_as(_ip), M, _d(Rf),
-                      res.ctypes.data_as(_ip))
+    L.vo_run_steps_mt_flavour(arr, nf, int(threads), steps, _d(u), float(dt), _d(z), slot.ctypes.data_as(_ip), M, _d(Rf),
+                              res.ctypes.data_as(_ip), 1 if structured else 0)
     return res

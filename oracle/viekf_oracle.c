@@ -881,24 +881,223 @@ int vo_negative_depth(const vo_filter *f) {
   return 0;
 }
 
+/* ------------------------------------------------------------------ "structured" CPU flavour (cpu_baseline only)
+ *
+ * SURVEY.md 8(d) / BASELINE.md 3 name two CPU baselines: (i) the dense reference-order algorithm above and (ii) the
+ * block-sparse / rank-2 formulation the HIP kernels use.  This is (ii): the same results up to rounding (checked against
+ * the dense flavour in tests/test_oracle_structured.py), O(n^2) instead of O(n^3) per call.
+ *   A = [[A_bb 0],[A_fb blkdiag(A_ff)]]  (vi_ekf_dyn.cpp:55-71,121-128)  =>  Phi, M of vi_ekf.cpp:302-303 have that shape;
+ *   a FEAT H has one 2x2 block (vi_ekf_meas.cpp:366)  =>  W = P H^T is two columns of P, and for symmetric P
+ *   (I-KH) P (I-KH)^T + K R K^T = P - K W^T  (vi_ekf_meas.cpp:256-257,265).
+ */
+static void mm3(const double *A, const double *B, double *C) { mm(3, 3, 3, A, 3, B, 3, C, 3); }
+
+void vo_propagate_structured(vo_filter *f, const double *u_imu, double dt) {
+  const int n = f->n, N = f->N, nb = 16;
+  double ub[6];
+  vo_q_rota(f->q_b_u, u_imu + VO_uA, ub + VO_uA);
+  vo_q_rota(f->q_b_u, u_imu + VO_uG, ub + VO_uG);
+  vo_dynamics(f, f->x, ub, 1, 1);
+  double *sdx = f->T3;
+  for (int i = 0; i < n; i++) sdx[i] = f->dx[i] * dt;
+  vo_boxplus(f, f->x, sdx, f->xp);
+  memcpy(f->x, f->xp, sizeof(double) * (size_t)(VO_xZ + 5 * f->len_features));
+  const double *A = f->A, *G = f->G;
+  /* body blocks */
+  double Abb[256], Abb2[256], Phibb[256], Mbb[256];
+  for (int j = 0; j < nb; j++) for (int i = 0; i < nb; i++) Abb[i + j * nb] = AT(A, n, i, j);
+  mm(nb, nb, nb, Abb, nb, Abb, nb, Abb2, nb);
+  for (int j = 0; j < nb; j++) for (int i = 0; i < nb; i++) {
+    const double id = (i == j) ? 1.0 : 0.0;
+    Phibb[i + j * nb] = id + Abb[i + j * nb] * dt + Abb2[i + j * nb] * dt * dt / 2.0;
+    Mbb[i + j * nb] = id + Abb[i + j * nb] * dt / 2.0 + Abb2[i + j * nb] * dt * dt / 6.0;
+  }
+  /* Gd (n x 6) in T3:  body rows M_bb G_b dt,  feature rows (M_fb G_b + M_ff G_f) dt */
+  double *Gd = f->T3;
+  double Gb[96];
+  for (int k = 0; k < 6; k++) for (int i = 0; i < nb; i++) Gb[i + k * nb] = AT(G, n, i, k);
+  for (int k = 0; k < 6; k++) for (int i = 0; i < nb; i++) {
+    double s = 0.0;
+    for (int c = 0; c < nb; c++) s += Mbb[i + c * nb] * Gb[c + k * nb];
+    AT(Gd, n, i, k) = s * dt;
+  }
+  /* per feature: Phi_fb (3 x 16), Phi_ff (3 x 3) kept in T1: [N][3*16 + 9] */
+  double *PF = f->T1;
+  for (int ft = 0; ft < N; ft++) {
+    const int r0 = nb + 3 * ft;
+    double Afb[48], Aff[9], Aff2[9], A2fb[48], t[48];
+    for (int c = 0; c < nb; c++) for (int r = 0; r < 3; r++) Afb[r + 3 * c] = AT(A, n, r0 + r, c);
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) Aff[r + 3 * c] = AT(A, n, r0 + r, r0 + c);
+    mm3(Aff, Aff, Aff2);
+    mm(3, nb, nb, Afb, 3, Abb, nb, A2fb, 3);
+    mm(3, 3, nb, Aff, 3, Afb, 3, t, 3);
+    double *Phifb = PF + (size_t)ft * 57, *Phiff = Phifb + 48;
+    double Mfb[48], Mff[9];
+    for (int e = 0; e < 48; e++) {
+      const double a2 = A2fb[e] + t[e];
+      Phifb[e] = Afb[e] * dt + a2 * dt * dt / 2.0;
+      Mfb[e] = Afb[e] * dt / 2.0 + a2 * dt * dt / 6.0;
+    }
+    for (int e = 0; e < 9; e++) {
+      const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+      Phiff[e] = id + Aff[e] * dt + Aff2[e] * dt * dt / 2.0;
+      Mff[e] = id + Aff[e] * dt / 2.0 + Aff2[e] * dt * dt / 6.0;
+    }
+    for (int k = 0; k < 6; k++) for (int r = 0; r < 3; r++) {
+      double s = 0.0;
+      for (int c = 0; c < nb; c++) s += Mfb[r + 3 * c] * Gb[c + k * nb];
+      for (int c = 0; c < 3; c++) s += Mff[r + 3 * c] * AT(G, n, r0 + c, k);
+      AT(Gd, n, r0 + r, k) = s * dt;
+    }
+  }
+  /* T = Phi P (n x n) in T2:  body rows Phi_bb P[b,:],  feature rows Phi_fb P[b,:] + Phi_ff P[f,:] */
+  double *T = f->T2, *P = f->P;
+  for (int j = 0; j < n; j++) {
+    const double *pc = &AT(P, n, 0, j);
+    double *tc = &AT(T, n, 0, j);
+    for (int i = 0; i < nb; i++) {
+      double s = 0.0;
+      for (int c = 0; c < nb; c++) s += Phibb[i + c * nb] * pc[c];
+      tc[i] = s;
+    }
+    for (int ft = 0; ft < N; ft++) {
+      const double *Phifb = PF + (size_t)ft * 57, *Phiff = Phifb + 48;
+      const int r0 = nb + 3 * ft;
+      for (int r = 0; r < 3; r++) {
+        double s = 0.0;
+        for (int c = 0; c < nb; c++) s += Phifb[r + 3 * c] * pc[c];
+        for (int c = 0; c < 3; c++) s += Phiff[r + 3 * c] * pc[r0 + c];
+        tc[r0 + r] = s;
+      }
+    }
+  }
+  /* P+ = T Phi^T:  body columns T[:,b] Phi_bb^T,  feature columns T[:,b] Phi_fb^T + T[:,f] Phi_ff^T */
+  for (int j = 0; j < nb; j++) {
+    double *pc = &AT(P, n, 0, j);
+    for (int i = 0; i < n; i++) pc[i] = 0.0;
+    for (int c = 0; c < nb; c++) {
+      const double ph = Phibb[j + c * nb];
+      const double *tc = &AT(T, n, 0, c);
+      for (int i = 0; i < n; i++) pc[i] += tc[i] * ph;
+    }
+  }
+  for (int ft = 0; ft < N; ft++) {
+    const double *Phifb = PF + (size_t)ft * 57, *Phiff = Phifb + 48;
+    const int r0 = nb + 3 * ft;
+    for (int r = 0; r < 3; r++) {
+      double *pc = &AT(P, n, 0, r0 + r);
+      for (int i = 0; i < n; i++) pc[i] = 0.0;
+      for (int c = 0; c < nb; c++) {
+        const double ph = Phifb[r + 3 * c];
+        const double *tc = &AT(T, n, 0, c);
+        for (int i = 0; i < n; i++) pc[i] += tc[i] * ph;
+      }
+      for (int c = 0; c < 3; c++) {
+        const double ph = Phiff[r + 3 * c];
+        const double *tc = &AT(T, n, 0, r0 + c);
+        for (int i = 0; i < n; i++) pc[i] += tc[i] * ph;
+      }
+    }
+  }
+  /* + Gd Qu Gd^T + Qx */
+  double *GQ = f->T1; /* n x 6 (PF is dead) */
+  mm(n, 6, 6, Gd, n, f->Qu, 6, GQ, n);
+  for (int j = 0; j < n; j++) {
+    double *pc = &AT(P, n, 0, j);
+    const double *qc = &AT(f->Qx, n, 0, j);
+    for (int k = 0; k < 6; k++) {
+      const double g = AT(Gd, n, j, k);
+      const double *gq = &AT(GQ, n, 0, k);
+      for (int i = 0; i < n; i++) pc[i] += gq[i] * g;
+    }
+    for (int i = 0; i < n; i++) pc[i] += qc[i];
+  }
+  memcpy(f->G, Gd, sizeof(double) * (size_t)n * 6);
+  vo_fix_depth(f);
+}
+
+/* active FEAT update, vi_ekf_meas.cpp:196-278 in its rank-2 form */
+int vo_update_feat_structured(vo_filter *f, const double *z, const double *R, int id) {
+  const int n = f->n;
+  double *H3 = f->H, *K3 = f->K, *P = f->P;
+  memset(f->zhat, 0, sizeof f->zhat);
+  vo_h(f, VO_FEAT, f->x, f->zhat, H3, id);
+  const int slot = vo_global_to_local_feature_id(f, id);
+  const int j0 = VO_dxZ + 3 * slot;
+  const double res[2] = {z[0] - f->zhat[0], z[1] - f->zhat[1]};
+  const double h00 = AT(H3, 3, 0, j0), h01 = AT(H3, 3, 0, j0 + 1), h10 = AT(H3, 3, 1, j0), h11 = AT(H3, 3, 1, j0 + 1);
+  double *W = f->T1; /* n x 2 */
+  const double *p0 = &AT(P, n, 0, j0), *p1 = &AT(P, n, 0, j0 + 1);
+  for (int i = 0; i < n; i++) {
+    W[i] = p0[i] * h00 + p1[i] * h01;
+    W[i + n] = p0[i] * h10 + p1[i] * h11;
+  }
+  double S[4], Sinv[4];
+  S[0] = h00 * W[j0] + h01 * W[j0 + 1] + R[0];
+  S[1] = h10 * W[j0] + h11 * W[j0 + 1] + R[1];
+  S[2] = h00 * W[j0 + n] + h01 * W[j0 + 1 + n] + R[2];
+  S[3] = h10 * W[j0 + n] + h11 * W[j0 + 1 + n] + R[3];
+  small_inverse(2, S, Sinv);
+  const double t0 = res[0] * Sinv[0] + res[1] * Sinv[1], t1 = res[0] * Sinv[2] + res[1] * Sinv[3];
+  if (t0 * res[0] + t1 * res[1] > 9.0) return VO_MEAS_GATED;
+  int nan_free = 1;
+  for (int i = 0; i < n; i++) {
+    const double k0 = W[i] * Sinv[0] + W[i + n] * Sinv[1], k1 = W[i] * Sinv[2] + W[i + n] * Sinv[3];
+    K3[i] = k0; K3[i + n] = k1;
+    if (k0 != k0 || k1 != k1) nan_free = 0;
+  }
+  if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) nan_free = 0;
+  if (nan_free) {
+    double *dxv = f->dx;
+    for (int i = 0; i < n; i++) {
+      const double l = f->use_partial_update ? f->lambda[i] : 1.0;
+      dxv[i] = (l * K3[i]) * res[0] + (l * K3[i + n]) * res[1];
+    }
+    vo_boxplus(f, f->x, dxv, f->xp);
+    memcpy(f->x, f->xp, sizeof(double) * (size_t)(VO_xZ + 5 * f->len_features));
+    for (int j = 0; j < n; j++) {
+      const double w0 = W[j], w1 = W[j + n], lj = f->lambda[j];
+      double *pc = &AT(P, n, 0, j);
+      if (f->use_partial_update) {
+        for (int i = 0; i < n; i++) {
+          const double li = f->lambda[i];
+          pc[i] -= (li + lj - li * lj) * (K3[i] * w0 + K3[i + n] * w1);
+        }
+      } else {
+        for (int i = 0; i < n; i++) pc[i] -= K3[i] * w0 + K3[i + n] * w1;
+      }
+    }
+  }
+  vo_fix_depth(f);
+  return VO_MEAS_SUCCESS;
+}
+
 /* ------------------------------------------------------------------ step drivers */
 
-void vo_run_steps(vo_filter *f, int steps, const double *u, double dt, const double *z, const int *slot, int M,
-                  const double *R, int *results) {
+
+static void run_steps_flavour(vo_filter *f, int steps, const double *u, double dt, const double *z, const int *slot, int M,
+                              const double *R, int *results, int structured) {
   for (int s = 0; s < steps; s++) {
-    vo_propagate(f, u + 6 * (size_t)s, dt);
+    if (structured) vo_propagate_structured(f, u + 6 * (size_t)s, dt);
+    else vo_propagate(f, u + 6 * (size_t)s, dt);
     for (int m = 0; m < M; m++) {
       int sl = slot[m];
       int res;
       if (sl < 0 || sl >= f->len_features) res = VO_MEAS_INVALID;
+      else if (structured) res = vo_update_feat_structured(f, z + 2 * ((size_t)s * M + m), R, f->feature_ids[sl]);
       else res = vo_update(f, VO_FEAT, z + 2 * ((size_t)s * M + m), 2, R, 2, 1, f->feature_ids[sl]);
       if (results) results[(size_t)s * M + m] = res;
     }
   }
 }
 
+void vo_run_steps(vo_filter *f, int steps, const double *u, double dt, const double *z, const int *slot, int M,
+                  const double *R, int *results) {
+  run_steps_flavour(f, steps, u, dt, z, slot, M, R, results, 0);
+}
+
 typedef struct {
-  vo_filter **fs; int lo, hi, steps, M, nf;
+  vo_filter **fs; int lo, hi, steps, M, nf, structured;
   const double *u, *z, *R; const int *slot; double dt; int *results;
 } mt_job;
 
@@ -906,21 +1105,26 @@ static void *mt_worker(void *arg) {
   mt_job *j = (mt_job *)arg;
   for (int k = j->lo; k < j->hi; k++) {
     /* per-filter inputs: u [nf][steps][6], z [nf][steps][M][2], slot [nf][M], results [nf][steps][M] */
-    vo_run_steps(j->fs[k], j->steps, j->u + (size_t)k * j->steps * 6, j->dt,
-                 j->z + (size_t)k * j->steps * j->M * 2, j->slot + (size_t)k * j->M, j->M, j->R,
-                 j->results ? j->results + (size_t)k * j->steps * j->M : NULL);
+    run_steps_flavour(j->fs[k], j->steps, j->u + (size_t)k * j->steps * 6, j->dt,
+                      j->z + (size_t)k * j->steps * j->M * 2, j->slot + (size_t)k * j->M, j->M, j->R,
+                      j->results ? j->results + (size_t)k * j->steps * j->M : NULL, j->structured);
   }
   return NULL;
 }
 
 void vo_run_steps_mt(vo_filter **fs, int nf, int threads, int steps, const double *u, double dt, const double *z,
                      const int *slot, int M, const double *R, int *results) {
+  vo_run_steps_mt_flavour(fs, nf, threads, steps, u, dt, z, slot, M, R, results, 0);
+}
+
+void vo_run_steps_mt_flavour(vo_filter **fs, int nf, int threads, int steps, const double *u, double dt, const double *z,
+                             const int *slot, int M, const double *R, int *results, int structured) {
   if (threads < 1) threads = 1;
   if (threads > nf) threads = nf;
   pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
   mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
   for (int t = 0; t < threads; t++) {
-    mt_job j = {fs, (int)((long)nf * t / threads), (int)((long)nf * (t + 1) / threads), steps, M, nf, u, z, R, slot, dt, results};
+    mt_job j = {fs, (int)((long)nf * t / threads), (int)((long)nf * (t + 1) / threads), steps, M, nf, structured, u, z, R, slot, dt, results};
     jobs[t] = j;
     pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
   }

@@ -116,6 +116,13 @@ void vo_run_steps(vo_filter *f, int steps, const double *u, double dt, const dou
 void vo_run_steps_mt(vo_filter **fs, int nf, int threads, int steps, const double *u, double dt,
                      const double *z, const int *slot, int M, const double *R, int *results);
 
+/* "structured" CPU flavour: the block-sparse propagate and the rank-2 FEAT update the HIP
+ * kernels use, on the CPU -- second cpu_baseline figure of bench.py, checked against the dense flavour above */
+void vo_propagate_structured(vo_filter *f, const double *u_imu, double dt);
+int  vo_update_feat_structured(vo_filter *f, const double *z, const double *R, int id);
+void vo_run_steps_mt_flavour(vo_filter **fs, int nf, int threads, int steps, const double *u, double dt,
+                             const double *z, const int *slot, int M, const double *R, int *results, int structured);
+
 #ifdef __cplusplus
 }
 #endif

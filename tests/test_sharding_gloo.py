@@ -25,7 +25,9 @@ def _worker(rank, world, port, q):
     lo, hi = bench.shard(2048, world, rank)
     dist.barrier()
     secs = bench.reduce_times(1.0 + rank, world)   # rank 1 is the slow one
-    q.put((rank, lo, hi, secs))
+    # the run's one collective: {steps, seconds, bytes, max_rel_err} -> {sum, max, sum, max}
+    rec = bench.reduce_record((hi - lo) * 10, 1.0 + rank, 1000.0 * (rank + 1), 1e-12 * (rank + 1), world)
+    q.put((rank, lo, hi, secs, rec))
     dist.destroy_process_group()
 
 
@@ -42,6 +44,13 @@ def test_two_rank_shard_and_time_reduction():
         assert p.exitcode == 0
     assert res[0][1:3] == (0, 1024) and res[1][1:3] == (1024, 2048)     # contiguous, disjoint, complete
     assert res[0][3] == 2.0 and res[1][3] == 2.0                        # max over ranks on every rank
+    for r in res:                                                       # the four-field record, identical on every rank
+        assert r[4] == {"steps": 20480.0, "seconds": 2.0, "bytes": 3000.0, "max_rel_err": 2e-12}
+
+
+def test_single_rank_record_is_local():
+    import bench
+    assert bench.reduce_record(5, 0.5, 7.0, 1e-13, 1) == {"steps": 5.0, "seconds": 0.5, "bytes": 7.0, "max_rel_err": 1e-13}
 
 
 def test_shard_partitions_exactly():

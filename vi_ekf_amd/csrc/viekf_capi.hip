@@ -149,11 +149,14 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   const BlkLds BL(b->N, b->n, b->nxs);
   const size_t blds = sizeof(double) * (size_t)BL.total;
   if (blocked_ok && M >= 2 && b->n <= 512 && blds + 1024 <= 160 * 1024) {   // (+ the kernel's small static LDS)
-    static size_t attr_bytes = 0;
-    if (blds > attr_bytes) {
+    // (a function attribute belongs to the DEVICE's copy of the kernel: one high-water mark per device, so that a process
+    //  driving several GPUs through hipSetDevice raises the limit on each of them)
+    static size_t attr_bytes[64] = {};
+    size_t& have = attr_bytes[b->device & 63];
+    if (blds > have) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_feat_blocked<512>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
-      attr_bytes = blds;
+      have = blds;
     }
     hipLaunchKernelGGL(k_update_feat_blocked<512>, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb,
                        rsm, d_res);
