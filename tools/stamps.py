@@ -11,7 +11,8 @@ import torch  # noqa
 import vi_ekf_amd as v
 from vi_ekf_amd import scene, capi
 
-B, N = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 50
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 sc = scene.make_scene(B, N, 2, seed=3)
 g = v.BatchVIEKF(B, N, sc["params"])
 for i in range(N):

@@ -168,12 +168,13 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   return VIEKF_OK;
 }
 
-// Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the worker thread
-// grid is TR = ceil(N/RB) block-rows x TD = N/2 + 1 wrapped diagonals and must fit NW*64 threads.
+// Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the N (N + 1) / 2 owned
+// 3x3 blocks are dealt round-robin to the NW * 64 worker threads, at most RB per thread.
 struct ResInst { int RB, NW, nmin, nmax, max_lds_kb; };
 const ResInst kResInst[] = {
     {3, 2, 1, 25, 80},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
                      // runs under the other's sweeps
+    {7, 3, 26, 50, 80},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160},
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
@@ -183,7 +184,8 @@ typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const dou
 res_kernel_t res_kernel(int inst, bool multi = false) {   // multi: several propagates per launch (viekf_batch_step_n)
   switch (inst) {
     case 0: return multi ? k_step_resident<3, 2, true> : k_step_resident<3, 2, false>;
-    case 1: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
+    case 1: return multi ? k_step_resident<7, 3, true> : k_step_resident<7, 3, false>;
+    case 2: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
   }
   return nullptr;
 }
@@ -195,17 +197,16 @@ int setup_resident(viekf_batch* b) {
     const ResInst& r = kResInst[i];
     if (force && atoi(force) != i) continue;
     if (b->N < r.nmin || b->N > r.nmax) continue;
-    const int TR = (b->N + r.RB - 1) / r.RB, TC = b->N / 2 + 1;   // TC holds TD, the number of wrapped diagonals
-    if (TR * TC > r.NW * 64) continue;
+    const int TR = 0, TC = 0;   // (kernel arguments kept for the launch signature; the ownership map needs neither)
+    if (b->N * (b->N + 1) / 2 > r.RB * r.NW * 64 || b->N > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > (size_t)r.max_lds_kb * 1024) continue;
-    if (r.NW == 2 && !force) {   // two small workgroups per CU only pay when the batch fills the CUs more than once
+    if (r.NW <= 3 && !force) {   // two small workgroups per CU only pay when the batch fills the CUs more than once
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
       if (b->B <= cus) continue;
     }
-    if (L.Pbb - L.X < 4 * b->n) continue;   // the second gain-row buffer lives in the propagate-only scratch starting at X
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true)),
@@ -352,6 +353,7 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   d.min_depth = p->min_depth;
   d.use_drag_term = p->use_drag_term;
   d.use_partial_update = p->use_partial_update;
+  for (int i = 0; i < 6; i++) d.sqrtQu[i] = std::sqrt(p->Qu[i] > 0.0 ? p->Qu[i] : 0.0);
   const WsLayout L(b->N, b->n);
   b->ws_stride = L.total;
 #define ALLOC(ptr, bytes)                                                        \

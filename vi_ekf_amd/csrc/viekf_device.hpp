@@ -24,6 +24,7 @@ struct DevParams {  // shared by every filter of a batch (kernel argument, lives
   double min_depth;
   int use_drag_term;
   int use_partial_update;
+  double sqrtQu[6];  // sqrt(Qu): the fused step carries Gd sqrt(Qu), so that Gd Qu Gd^T is one symmetric product
 };
 
 #define VD __device__ __forceinline__

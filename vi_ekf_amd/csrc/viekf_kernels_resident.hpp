@@ -14,6 +14,8 @@
 // lambda_feat is the same for every feature slot (vi_ekf.cpp:139-144), so the partial-update
 // mask Lambda (vi_ekf.cpp:83,146) is ONE 3x3 constant for every feature/feature block.
 #pragma once
+#include <type_traits>
+
 #include "viekf_kernels_stream.hpp"
 
 namespace viekf {
@@ -21,33 +23,47 @@ namespace viekf {
 #ifndef RES_INLINE
 #define RES_INLINE __forceinline__
 #endif
-constexpr int XK = 38;  // contraction depth of the propagate GEMM: 16 (U) + 16 (Phi_fb) + 6 (Gd)
+// Propagate in low-rank coupling form.  A_fb[I] = Afv_I E_v + Afg_I E_g and the bias rows of A_bb are zero
+// (vi_ekf_dyn.cpp:55-71,121-128), so  Phi_fb[I] = D_I Psi  with a per-feature 3x9  D_I = [M1 | M3 | M2],
+//   M1 = (Afv + dt/2 Aff Afv) dt,  M3 = Afv dt^2/2,  M2 = (Afg + dt/2 Aff Afg) dt,   Psi = [E_v ; A_bb[vel rows] ; E_g]  (9 x 16),
+// and with  Pi = Psi P_bb Psi^T,  V_I = Phi_ff[I] P[I, body],  Ut_I = D_I Pi / 2 + V_I Psi^T  (3x9):
+//   P+[I,J] = Phi_ff[I] P[I,J] Phi_ff[J]^T + Ut_I D_J^T + D_I Ut_J^T + Gs_I Gs_J^T (+ Qx),   Gs = Gd sqrt(Qu)
+//   P+[I,body] = V_I Phi_bb^T + D_I Xi + Gs_I Gs_b^T,   Xi = Psi (P_bb Phi_bb^T)
+// -- a K = 24 contraction over ONE record per row (the symmetric form needs no separate X / Y operands):
+//   Z[row] = { (Ut[k], D[k]) k = 0..8 interleaved | Gs[0..5] | pad }      ZS doubles per row
+constexpr int ZK = 9;    // rank of the feature/body coupling
+constexpr int ZS = 26;   // row stride of Z: 6 ZS = 28 (mod 64 dwords), consecutive features land on distinct 16-byte bank groups
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, X, Y, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, featA, mslot, mseq, mz, mR, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, PsiP, Pi, Xi, AvG, mslot, mseq, mz, mR, img_len, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
-    Kt = take(2 * n); Wt = take(2 * n);
-    Praw = take(4 * n > 256 ? 4 * n : 256);   // [n][2] raw columns of the next measurement, then [2][16][2] stashed body rows;
-                                              // doubles as the 16x16 scratch T16 of the propagate
     lam = take(n);
     sm = take(64);   // [0..15],[16..31] two measurement mailboxes {Hb(4) res(2) Sinv(4) verdict}, [40..41] fix mailboxes
                      // non-empty, [42] dt, [44..46] NaN-guard words (phase mod 3), [49] count of worker waves that have
                      // published the next raw columns (int), [50..51] gate verdicts (phase parity)
-    Pd = take(4 * (N > 0 ? N : 1));   // zeta-zeta 2x2 diagonal blocks, handed from the workers to the service lanes
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
-    X = take(nf * XK); Y = take(nf * XK);
+    // Z, Phi_ff and the two-lives region are contiguous: at store time all of it is dead and holds the P image
+    Z = take(nf * ZS > 4 * n ? nf * ZS : 4 * n);   // propagate: the records; updates: second gain-row buffer; store: P image
     phiff = take(9 * (N > 0 ? N : 1));
-    Abb = take(256); Gb = take(96); Phibb = take(256); Mbb = take(256); Gdb = take(96); Pbb = take(256);
-    T16 = Praw;   // 16x16 scratch of the propagate only: shares storage with the (update-phase) column buffers
+    // one region, two lives: the propagate's body-sized scratch | the update loop's gain rows, raw columns and zeta blocks
+    const int u0 = o;
+    Abb = take(256); Gb = take(96); Phibb = take(256); PhibbT = take(256); Gdb = take(96); T16 = take(256);
+    PsiP = take(ZK * 16); Pi = take(ZK * ZK); Xi = take(ZK * 16); AvG = take(18);
+    const int uprop = o;
+    o = u0;
+    Kt = take(2 * n); Wt = take(2 * n);
+    Praw = take(4 * n > 256 ? 4 * n : 256);   // two buffers [n][2]: raw column pairs of the next two measurements
+    Pd = take(4 * (N > 0 ? N : 1));           // zeta-zeta 2x2 diagonal blocks, handed from the workers to the service lanes
+    if (uprop > o) o = uprop;
+    img_len = o - Z;
+    Mbb = take(256); Pbb = take(256);
     xdb = take(16);
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
     Pbc = take(nf * 16);
-    PhibbT = take(256);
-    featA = take(36 * (N > 0 ? N : 1));
     mslot = take(32); mseq = take(64); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
@@ -68,39 +84,84 @@ __device__ RES_INLINE void res_body_phase(const double* xs, const double* u, con
   *ctx = c;
 }
 
-// one feature's share of the propagate set-up on the SERVICE wave: dynamics, Phi_ff, state step.  The 3x16 rows of Phi_fb
-// and the input-noise rows Gd_f (both need the body Jacobian) are finished by the worker waves from featA:
-//   featA[f] = { Afv(9), Afg(9), Aff(9), Gff(9) }   with Gff = (I + Aff dt/2 + Aff^2 dt^2/6) Afg
-constexpr int FEATA = 36;
-__device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* xs, const BodyCtx* ctx, double* featA,
+// one feature's share of the propagate set-up on the SERVICE wave: dynamics, Phi_ff, state step.  The Jacobian blocks are
+// handed to the worker waves RAW, in the EVEN slots of the feature's own three Z rows (row r, slot 2c: c = 0..2 Afv[r][c],
+// 3..5 Afg[r][c-3], 6..8 Aff[r][c-6]); a worker thread per row expands them into D and Gs (res_feature_expand_row: odd slots
+// and 18..23, so nothing it reads is overwritten), off this wave's serial path.  The even slots receive Ut afterwards.
+__device__ RES_INLINE void res_feature_phase(int f, int len, double dt, double* xs, const BodyCtx* ctx, double* Z,
                                              double* phiff) {
-  double* fa = featA + FEATA * f;
+  double* z0 = Z + (3 * f) * ZS;
   if (f < len) {
     double xd3[3], Afv[9], Afg[9], Aff[9];
     const double qz[4] = {xs[xZ + 5 * f], xs[xZ + 5 * f + 1], xs[xZ + 5 * f + 2], xs[xZ + 5 * f + 3]};
     const double rho = xs[xZ + 5 * f + 4];
     const BodyCtx c = *ctx;   // (a register copy: the stores below may alias the LDS one as far as the compiler knows)
     feature_dynamics(qz, rho, c, xd3, Afv, Afg, Aff);
-    double Aff2[9], Mff[9], Gff[9];
+    double Aff2[9];
     mm<3, 3, 3>(Aff, Aff, Aff2);
 #pragma unroll
     for (int e = 0; e < 9; e++) {
       const double id = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
-      // (dt^2/6 as one factor: a true division per element is ~15 dependent instructions; 1 ulp from the reference's order)
-      Mff[e] = id + Aff[e] * (0.5 * dt) + Aff2[e] * (dt * dt * (1.0 / 6.0));
       phiff[9 * f + e] = id + Aff[e] * dt + Aff2[e] * (0.5 * dt * dt);
     }
-    mm<3, 3, 3>(Mff, Afg, Gff);
 #pragma unroll
-    for (int e = 0; e < 9; e++) { fa[e] = Afv[e]; fa[9 + e] = Afg[e]; fa[18 + e] = Aff[e]; fa[27 + e] = Gff[e]; }
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c3 = 0; c3 < 3; c3++) {
+        z0[r * ZS + 2 * c3] = Afv[r * 3 + c3]; z0[r * ZS + 2 * (3 + c3)] = Afg[r * 3 + c3]; z0[r * ZS + 2 * (6 + c3)] = Aff[r * 3 + c3];
+      }
     double qn[4];
     q_feat_boxplus_fast(qz, xd3[0] * dt, xd3[1] * dt, qn);
     double* xf = xs + xZ + 5 * f;
     xf[0] = qn[0]; xf[1] = qn[1]; xf[2] = qn[2]; xf[3] = qn[3];
     xf[4] = rho + xd3[2] * dt;
   } else {  // inactive slot: Phi = I, G = 0
-    for (int e = 0; e < FEATA; e++) fa[e] = 0.0;
+    for (int r = 0; r < 3; r++)
+      for (int e = 0; e < 9; e++) z0[r * ZS + 2 * e] = 0.0;
     for (int e = 0; e < 9; e++) phiff[9 * f + e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+  }
+}
+
+// Worker side of the hand-over, one thread per row r of feature f: the raw blocks (see above) -> row r of
+//   D = [M1 | M3 | M2]  in the odd slots 2k+1,  Gs = Gd_f sqrt(Qu)  in slots 18..23, with
+//   Gd_f = dt ((dt/2) (Afv + dt/3 Aff Afv) G_b[vel rows] + (dt^2/6) Afv (A_v G_b) + [0 | (I + Aff dt/2 + Aff^2 dt^2/6) Afg])
+//   (vi_ekf.cpp:302 restricted to the feature rows; G_b has no bias rows, vi_ekf_dyn.cpp:74-79)
+// (row-wise, operands re-read from LDS: the whole-feature form held ~100 doubles live next to the thread's blocks of P)
+__device__ RES_INLINE void res_feature_expand_row(int f, int r, double dt, double* Z, const double* Gb, const double* AvG,
+                                                  const double* sqrtQu) {
+  const double* z0 = Z + (3 * f) * ZS;
+  double* zr = Z + (3 * f + r) * ZS;
+  auto raw = [&](int row, int c) { return z0[row * ZS + 2 * c]; };   // c: 0..2 Afv, 3..5 Afg, 6..8 Aff
+  const double a0 = raw(r, 6), a1 = raw(r, 7), a2 = raw(r, 8);       // Aff[r][:]
+  double AAv[3], AAg[3], A2r[3], afv[3], afg[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    afv[j] = raw(r, j); afg[j] = raw(r, 3 + j);
+    AAv[j] = a0 * raw(0, j) + a1 * raw(1, j) + a2 * raw(2, j);
+    AAg[j] = a0 * raw(0, 3 + j) + a1 * raw(1, 3 + j) + a2 * raw(2, 3 + j);
+    A2r[j] = a0 * raw(0, 6 + j) + a1 * raw(1, 6 + j) + a2 * raw(2, 6 + j);
+  }
+  const double ar[3] = {a0, a1, a2};
+  double mff[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) mff[j] = ((j == r) ? 1.0 : 0.0) + ar[j] * (0.5 * dt) + A2r[j] * (dt * dt * (1.0 / 6.0));
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      a += (afv[j] + (dt * (1.0 / 3.0)) * AAv[j]) * Gb[(dxVEL + j) * 6 + k];
+      b += afv[j] * AvG[j * 6 + k];
+    }
+    double g = a * (0.5 * dt) + b * (dt * dt * (1.0 / 6.0));
+    if (k >= 3) g += mff[0] * raw(0, k) + mff[1] * raw(1, k) + mff[2] * raw(2, k);   // (Mff Afg)[r][k-3]
+    zr[18 + k] = g * dt * sqrtQu[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    zr[2 * j + 1] = (afv[j] + (0.5 * dt) * AAv[j]) * dt;          // M1
+    zr[2 * (3 + j) + 1] = afv[j] * (0.5 * dt * dt);               // M3
+    zr[2 * (6 + j) + 1] = (afg[j] + (0.5 * dt) * AAg[j]) * dt;    // M2
   }
 }
 
@@ -143,6 +204,23 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// Many blocks per thread: fences the operand loads of one group of blocks from the next (a compiler-level memory barrier plus
+// a scheduling barrier) -- otherwise every block's (mutually independent) LDS reads are hoisted to the top and their results
+// held live together, which does not fit the register file next to the blocks themselves.
+// 16-byte LDS read as ONE vector load: through HIP's double2 struct the two halves are often split and re-paired as
+// ds_read2_b64 (8 LDS cycles per wave instruction, 32-bank mapping) instead of ds_read_b128 (4 cycles, 64 banks)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 lds_ld2(const double* p) {
+  const v2f64 v = *reinterpret_cast<const v2f64*>(p);
+  return make_double2(v.x, v.y);
+}
+template <bool ON>
+__device__ __forceinline__ void group_fence() {
+  if (ON) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-uniform double into SGPRs
   const unsigned long long u = __double_as_longlong(v);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -167,12 +245,12 @@ constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lis
 typedef __attribute__((address_space(3))) volatile int lds_vint_t;
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
-  double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *X, *Y, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
-      *xdb, *Pbc, *PhibbT, *Pd, *featA, *mz, *mR;
+  double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *Z, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
+      *xdb, *Pbc, *PhibbT, *Pd, *PsiP, *Pi, *Xi, *AvG, *mz, *mR;
   int* mslot;   // [MCAP] slot, or -1 for a measurement that is not run
   int2* mseq;   // [MCAP] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
-  int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B;   // kp: propagates per launch (viekf_batch_step_n)
+  int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B, img_len;   // kp: propagates per launch (viekf_batch_step_n)
   double* stamps;
 };
 
@@ -183,216 +261,217 @@ __device__ __forceinline__ int res_next_valid(const ResShared& S, int from) {
   return m;
 }
 
-// Propagate set-up shared by the worker layouts (LDS only): Phi_bb, Phi_fb rows, Gd rows, U and V  ->  X, Y, T16, Gdb ...
+// Propagate set-up on the worker waves (LDS only; see the header of this file for the algebra).  Three intervals:
+//   [B1p..B2p]  Phi_bb / M_bb, the per-feature expansion raw blocks -> D, Gs, V = Phi_ff P[feat, body] (in place), Psi P_bb
+//   [B2p..B2q]  Gs_b = M_bb G_b dt sqrt(Qu), T16 = Phi_bb P_bb, Pi = Psi P_bb Psi^T
+//   [B2q..B3p]  Ut = D Pi / 2 + V Psi^T  (the even Z slots), Xi = Psi T16^T
 // Barriers B1p, B2p, B2q inside; the caller continues with B3p.
 template <int TW>
 __device__ __forceinline__ void res_prop_setup(const StreamArgs& a, const ResShared& S, int tid) {
-  const int nf = S.nf;
+  const int nf = S.nf, N = S.N;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc; double* Pbb = S.Pbb;
-  double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
+  double* Z = S.Z; double* phiff = S.phiff;
   double* Phibb = S.Phibb; double* Mbb = S.Mbb; double* Gdb = S.Gdb; double* T16 = S.T16;
-    __syncthreads();  // B1p : body Jacobian ready (service), and this propagate's dt
+  __syncthreads();  // B1p : body Jacobian, raw feature blocks and Phi_ff ready (service), and this propagate's dt
   const double dt = S.sm[42];
 
-    for (int e = tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303)
-      const int r = e >> 4, c = e & 15;
-      double a2 = 0.0;
+  // ---- [B1p..B2p]
+  for (int e = tid; e < nf; e += TW) res_feature_expand_row(e / 3, e % 3, dt, Z, S.Gb, S.AvG, prm.sqrtQu);
+  for (int e = TW - 1 - tid; e < 256; e += TW) {   // body transition blocks (vi_ekf.cpp:302-303), from the last threads
+    const int r = e >> 4, c = e & 15;
+    double a2 = 0.0;
 #pragma unroll 4
-      for (int k = 0; k < 16; k++) a2 += S.Abb[r * 16 + k] * S.Abb[k * 16 + c];
-      const double id = (r == c) ? 1.0 : 0.0, av = S.Abb[e];
-      Mbb[e] = id + av * (0.5 * dt) + a2 * (dt * dt * (1.0 / 6.0));
-      const double ph = id + av * dt + a2 * (0.5 * dt * dt);
-      Phibb[e] = ph;
-      S.PhibbT[c * 16 + r] = ph;   // transposed copy: lanes that differ in the OUTPUT column read consecutive words
-    }
-    __syncthreads();  // B2p : feature Jacobian blocks featA / Phi_ff ready (service), Phi_bb ready (workers)
-
-    // Phi_fb rows (vi_ekf.cpp:302-303 restricted to the feature/body block): one (feature row, body column) per item
-    //   A_fb = [.. Afv(VEL) .. Afg(B_G) ..],  (A^2)_fb = A_fb A_bb + A_ff A_fb
-    // (a thread's items all have the same body column c -- TW is a multiple of 16 --: its six A_bb entries are read once)
-    double abv[3], abg[3];
-    {
-      const int c = tid & 15;
-#pragma unroll
-      for (int k = 0; k < 3; k++) { abv[k] = S.Abb[(dxVEL + k) * 16 + c]; abg[k] = S.Abb[(dxB_G + k) * 16 + c]; }
-    }
-#pragma unroll 1
-    for (int e = tid; e < nf * 16; e += TW) {
-      const int row = e >> 4, c = e & 15, f = row / 3, r = row - 3 * f;
-      const double* fa = S.featA + FEATA * f;
-      const bool cv = c >= dxVEL && c < dxVEL + 3, cg = c >= dxB_G && c < dxB_G + 3;
-      const int cc = cv ? (c - dxVEL) : (cg ? (c - dxB_G) : 0);
-      const double* blk3 = cv ? fa : fa + 9;            // Afv or Afg
-      const double afb = (cv || cg) ? blk3[r * 3 + cc] : 0.0;
-      double a2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; k++) a2 += fa[r * 3 + k] * abv[k] + fa[9 + r * 3 + k] * abg[k];
-      if (cv || cg) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) a2 += fa[18 + r * 3 + k] * blk3[k * 3 + cc];
-      }
-      const double ph = afb * dt + a2 * (0.5 * dt * dt);
-      X[row * XK + 16 + c] = ph;
-      Y[row * XK + c] = ph;
-    }
-    __syncthreads();  // B2q
-
-    // Two products share the operand Phi_fb (nf x 16, in Y[.,0..15]) and run on the matrix cores, one 16-row tile per wave
-    // and turn (v_mfma_f64_16x16x4_f64, 4 k-steps each; the VALU form of these loops was LDS-bound, 16 k clk per step):
-    //   Phi_fb G_b   (nf x 6)  -> input-noise rows Gd_f = (M_fb G_b + [0 | Gff]) dt -> Y[.,32..37], times Qu -> X[.,32..37]
-    //                             (vi_ekf.cpp:302), with M_fb = A_fb dt/2 + (A^2)_fb dt^2/6 = Phi_fb / 3 + A_fb dt/6
-    //   Phi_fb P_bb  (nf x 16) -> U = (Phi P)[feat, body] = Phi_fb P_bb + Phi_ff P[feat, body] -> X[.,0..15];
-    //                             V_J = Phi_ff[J] P[J, body] -> Y[.,16..31]
-    // A result lane holds column lr = lane & 15 of rows lk + 4 r (lk = lane >> 4) of the tile.
-    {
-      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
-      // (everything that does not depend on the tile is read once: the compiler cannot hoist it itself, the stores to X / Y
-      //  below may alias it as far as it knows)
-      const int lq = min(lr, 5);
-      double bgv[4], buv[4], gbv[3], gbg[3];
-#pragma unroll
-      for (int sk = 0; sk < 4; sk++) {
-        const int c = 4 * sk + lk;
-        bgv[sk] = (lr < 6) ? S.Gb[c * 6 + lq] : 0.0;
-        buv[sk] = Pbb[c * 16 + lr];
-      }
-#pragma unroll
-      for (int j = 0; j < 3; j++) { gbv[j] = S.Gb[(dxVEL + j) * 6 + lq]; gbg[j] = S.Gb[(dxB_G + j) * 6 + lq]; }
-      const double quv = prm.Qu[lq], dt6 = dt * (1.0 / 6.0);
-      for (int t = wv; t * 16 < nf; t += TW / 64) {
-        v4f64 accG = {0.0, 0.0, 0.0, 0.0}, accU = {0.0, 0.0, 0.0, 0.0};
-        const double* arow = Y + min(16 * t + lr, nf - 1) * XK;
-#pragma unroll
-        for (int sk = 0; sk < 4; sk++) {
-          const double av = arow[4 * sk + lk];
-          accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bgv[sk], accG, 0, 0, 0);
-          accU = __builtin_amdgcn_mfma_f64_16x16x4f64(av, buv[sk], accU, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-          const int row = 16 * t + lk + 4 * r4;
-          if (row < nf) {
-            const int f = row / 3, r = row - 3 * f;
-            const double* fa = S.featA + FEATA * f;
-            if (lr < 6) {
-              double ga = 0.0;
-#pragma unroll
-              for (int j = 0; j < 3; j++) ga += fa[r * 3 + j] * gbv[j] + fa[9 + r * 3 + j] * gbg[j];
-              double g = accG[r4] * (1.0 / 3.0) + ga * dt6;
-              if (lr >= 3) g += fa[27 + r * 3 + (lr - 3)];
-              g *= dt;
-              Y[row * XK + 32 + lr] = g;
-              X[row * XK + 32 + lr] = g * quv;
-            }
-            double sv = 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; m++) sv += phiff[9 * f + r * 3 + m] * Pbc[(3 * f + m) * 16 + lr];
-            X[row * XK + lr] = accU[r4] + sv;    // U
-            Y[row * XK + 16 + lr] = sv;          // V
-          }
-        }
-      }
-    }
-    // (the two small body products go to the LAST waves: the first ones have a second tile below)
-    for (int e = TW - 1 - tid; e < 96; e += TW) {
-      const int r = e / 6, k = e % 6;
-      double s = 0.0;
+    for (int k = 0; k < 16; k++) a2 += S.Abb[r * 16 + k] * S.Abb[k * 16 + c];
+    const double id = (r == c) ? 1.0 : 0.0, av = S.Abb[e];
+    Mbb[e] = id + av * (0.5 * dt) + a2 * (dt * dt * (1.0 / 6.0));
+    const double ph = id + av * dt + a2 * (0.5 * dt * dt);
+    Phibb[e] = ph;
+    S.PhibbT[c * 16 + r] = ph;   // transposed copy: lanes that differ in the OUTPUT column read consecutive words
+  }
+  for (int e = TW - 1 - tid; e < ZK * 16; e += TW) {   // Psi P_bb: rows E_v, A_bb[vel rows], E_g of P_bb
+    const int q = e >> 4, c = e & 15;
+    double v;
+    if (q < 3) v = Pbb[(dxVEL + q) * 16 + c];
+    else if (q >= 6) v = Pbb[(dxB_G + q - 6) * 16 + c];
+    else {
+      v = 0.0;
 #pragma unroll 4
-      for (int c = 0; c < 16; c++) s += Mbb[r * 16 + c] * S.Gb[c * 6 + k];
-      Gdb[e] = s * dt;
+      for (int k = 0; k < 16; k++) v += S.Abb[(dxVEL + q - 3) * 16 + k] * Pbb[k * 16 + c];
     }
-    for (int e = TW - 1 - tid; e < 256; e += TW) {
-      const int r = e >> 4, c = e & 15;
-      double s = 0.0;
-#pragma unroll 4
-      for (int k = 0; k < 16; k++) s += Phibb[r * 16 + k] * Pbb[k * 16 + c];
-      T16[e] = s;
-    }
-}
+    S.PsiP[e] = v;
+  }
+  for (int e = tid; e < 16 * N; e += TW) {   // V = Phi_ff[f] P[f, body], in place: item = (feature f, body column k)
+    const int f = e >> 4, k = e & 15;
+    const double* ff = phiff + 9 * f;
+    double* pc = Pbc + (3 * f) * 16 + k;
+    const double p0 = pc[0], p1 = pc[16], p2 = pc[32];
+    pc[0] = ff[0] * p0 + ff[1] * p1 + ff[2] * p2;
+    pc[16] = ff[3] * p0 + ff[4] * p1 + ff[5] * p2;
+    pc[32] = ff[6] * p0 + ff[7] * p1 + ff[8] * p2;
+  }
+  __syncthreads();  // B2p
 
-// P+[feature rows, body columns] (in LDS, in place: each output needs only U, already in X) and the body block (-> Mbb)
-template <int TW>
-__device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShared& S, int tid) {
-  const int nf = S.nf;
-  const DevParams& prm = *a.dp;
-  double* Pbc = S.Pbc;
-  double* X = S.X; double* Gdb = S.Gdb; double* T16 = S.T16;
-    // ---- body columns (in LDS, in place: each output needs only U, already in X) and body block
-    // P+[16+row][k] = U[row,:] Phi_bb[k,:] + (Gd Qu)[row,:] Gd_b[k,:]  -- (nf x 22)(22 x 16) on the matrix cores, one 16-row tile
-    // per wave and turn, 6 k-steps (the last two hold the 6 input-noise columns, zero padded)
-    {
-      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
-      constexpr int step = TW / 64;
-      // the right-hand operands do not depend on the tile: loaded once; two tiles per turn, so that one tile's dependent
-      // MFMA chain runs in the shadow of the other's
-      double bph[4], bgd[2];
-#pragma unroll
-      for (int sk = 0; sk < 4; sk++) bph[sk] = S.PhibbT[(4 * sk + lk) * 16 + lr];
-#pragma unroll
-      for (int sk = 0; sk < 2; sk++) { const int c = 4 * sk + lk; bgd[sk] = (c < 6) ? Gdb[lr * 6 + c] : 0.0; }   // (c = 0..7, noise columns c < 6)
-      for (int t = wv; t * 16 < nf; t += 2 * step) {
-        const int t1 = t + step;
-        const double* xr0 = X + min(16 * t + lr, nf - 1) * XK;
-        const double* xr1 = X + min(16 * t1 + lr, nf - 1) * XK;
-        double a0[6], a1[6];
-#pragma unroll
-        for (int sk = 0; sk < 4; sk++) { a0[sk] = xr0[4 * sk + lk]; a1[sk] = xr1[4 * sk + lk]; }
-#pragma unroll
-        for (int sk = 0; sk < 2; sk++) {
-          const int c = 4 * sk + lk;
-          a0[4 + sk] = (c < 6) ? xr0[32 + c] : 0.0;
-          a1[4 + sk] = (c < 6) ? xr1[32 + c] : 0.0;
-        }
-        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int sk = 0; sk < 6; sk++) {
-          const double bv = sk < 4 ? bph[sk] : bgd[sk - 4];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sk], bv, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sk], bv, acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-          const int row0 = 16 * t + lk + 4 * r4, row1 = 16 * t1 + lk + 4 * r4;
-          if (row0 < nf) Pbc[row0 * 16 + lr] = acc0[r4];
-          if (row1 < nf) Pbc[row1 * 16 + lr] = acc1[r4];
-        }
-      }
+  // ---- [B2p..B2q]
+  for (int e = tid; e < 256; e += TW) {
+    const int r = e >> 4, c = e & 15;
+    double sv = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) sv += Phibb[r * 16 + k] * Pbb[k * 16 + c];
+    T16[e] = sv;
+  }
+  for (int e = TW - 1 - tid; e < 96; e += TW) {
+    const int r = e / 6, k = e % 6;
+    double sv = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < 16; c++) sv += Mbb[r * 16 + c] * S.Gb[c * 6 + k];
+    Gdb[e] = sv * dt * prm.sqrtQu[k];
+  }
+  for (int e = tid; e < ZK * ZK; e += TW) {   // Pi = (Psi P_bb) Psi^T
+    const int q = e / ZK, j = e - q * ZK;
+    const double* pr = S.PsiP + q * 16;
+    double v;
+    if (j < 3) v = pr[dxVEL + j];
+    else if (j >= 6) v = pr[dxB_G + j - 6];
+    else {
+      v = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < 16; k++) v += pr[k] * S.Abb[(dxVEL + j - 3) * 16 + k];
     }
-    // body block  P_bb+ = T16 Phi_bb^T + (Gd_b Qu) Gd_b^T + Qx : one 16 x 16 tile, 4 + 2 k-steps, on the first wave
-    // (as 256 x 22-term dot products it was the longest item of this function)
-    if (tid < 64) {
-      const int lr = tid & 15, lk = tid >> 4;
+    S.Pi[e] = v;
+  }
+  __syncthreads();  // B2q
+
+  // ---- [B2q..B3p]
+  // Ut = [D | V] [Pi / 2 ; Psi^T]  (nf x 25)(25 x 9) on the matrix cores, one 16-row tile per wave and turn, 7 k-steps (as
+  // 1350 dot products this interval was LDS-bound: 50 operand reads per output).  A result lane holds column lr = lane & 15
+  // of rows lk + 4 r (lk = lane >> 4) of the tile; columns 9..15 of the right-hand side are zero.
+  {
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    double bv[7];
+    int aoff[7];     // where k = 4 sk + lk sits: D[k] in the Z row (odd slots), V[k - 9] in the Pbc row, k >= 25: nowhere
+#pragma unroll
+    for (int sk = 0; sk < 7; sk++) {
+      const int k = 4 * sk + lk, c = k - ZK;
+      double v = 0.0;
+      if (lr < ZK) {
+        if (k < ZK) v = 0.5 * S.Pi[k * ZK + lr];
+        else if (c < 16) v = (lr < 3) ? ((c == dxVEL + lr) ? 1.0 : 0.0)
+                           : ((lr >= 6) ? ((c == dxB_G + lr - 6) ? 1.0 : 0.0) : S.Abb[(dxVEL + lr - 3) * 16 + c]);
+      }
+      bv[sk] = v;
+      aoff[sk] = (k < ZK) ? (2 * k + 1) : ((c < 16) ? (0x100 | c) : -1);
+    }
+    for (int t = wv; t * 16 < nf; t += TW / 64) {
+      const int ar = min(16 * t + lr, nf - 1);
       v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int sk = 0; sk < 4; sk++) {
-        const int k = 4 * sk + lk;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T16[lr * 16 + k], S.PhibbT[k * 16 + lr], acc, 0, 0, 0);   // rows r = lr | cols c = lr
-      }
-#pragma unroll
-      for (int sk = 0; sk < 2; sk++) {
-        const int k = 4 * sk + lk;                                   // 0..7, the input-noise columns are k < 6
-        const double av = (k < 6) ? Gdb[lr * 6 + k] * prm.Qu[k] : 0.0;
-        const double bv = (k < 6) ? Gdb[lr * 6 + k] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      for (int sk = 0; sk < 7; sk++) {
+        const int o = aoff[sk];
+        const double av = (o < 0) ? 0.0 : ((o & 0x100) ? Pbc[ar * 16 + (o & 0xff)] : Z[ar * ZS + o]);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[sk], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r4 = 0; r4 < 4; r4++) {
-        const int r = lk + 4 * r4, c = lr;                           // a result lane holds column lr of rows lk + 4 r4
-        S.Mbb[r * 16 + c] = acc[r4] + ((r == c) ? a.Qx[r] : 0.0);    // P_bb+ staged in Mbb (T16 / Pbb are still being read)
+        const int row = 16 * t + lk + 4 * r4;
+        if (row < nf && lr < ZK) Z[row * ZS + 2 * lr] = acc[r4];
       }
     }
+  }
+  for (int e = TW - 1 - tid; e < ZK * 16; e += TW) {   // Xi = Psi T16^T  (T16^T = P_bb Phi_bb^T)
+    const int q = e >> 4, c = e & 15;
+    double v;
+    if (q < 3) v = T16[c * 16 + dxVEL + q];
+    else if (q >= 6) v = T16[c * 16 + dxB_G + q - 6];
+    else {
+      v = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < 16; k++) v += S.Abb[(dxVEL + q - 3) * 16 + k] * T16[c * 16 + k];
+    }
+    S.Xi[e] = v;
+  }
+}
+
+// P+[feature rows, body columns] = V Phi_bb^T + D Xi + Gs Gs_b^T, in LDS and in place (a tile's rows are read before they are
+// written, by the same wave), and the body block (-> Mbb).  (nf x 16)(16 x 16) + (nf x 16)(16 x 16) on the matrix cores, one
+// 16-row tile per wave and turn, 4 + 4 k-steps: the second product's k runs over D[0..8], Gs[0..5] and one zero.
+template <int TW>
+__device__ __forceinline__ void res_prop_body(const StreamArgs& a, const ResShared& S, int tid) {
+  const int nf = S.nf;
+  double* Pbc = S.Pbc;
+  const double* Z = S.Z; double* Gdb = S.Gdb; double* T16 = S.T16;
+  {
+    const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    constexpr int step = TW / 64;
+    // the right-hand operands do not depend on the tile: loaded once; two tiles per turn, so that one tile's dependent
+    // MFMA chain runs in the shadow of the other's
+    double bph[4], bdx[4];
+    int zoff[4];   // slot of k = 4 sk + lk in a Z row: D[k] at 2k+1, Gs[k-9] at 18 + k - 9, k = 15: none
+#pragma unroll
+    for (int sk = 0; sk < 4; sk++) {
+      const int k = 4 * sk + lk;
+      bph[sk] = S.PhibbT[k * 16 + lr];
+      bdx[sk] = (k < ZK) ? S.Xi[k * 16 + lr] : ((k < ZK + 6) ? Gdb[lr * 6 + (k - ZK)] : 0.0);
+      zoff[sk] = (k < ZK) ? (2 * k + 1) : ((k < ZK + 6) ? (18 + k - ZK) : -1);
+    }
+    for (int t = wv; t * 16 < nf; t += 2 * step) {
+      const int t1 = t + step;
+      const int r0 = min(16 * t + lr, nf - 1), r1 = min(16 * t1 + lr, nf - 1);
+      double a0[8], a1[8];
+#pragma unroll
+      for (int sk = 0; sk < 4; sk++) {
+        a0[sk] = Pbc[r0 * 16 + 4 * sk + lk]; a1[sk] = Pbc[r1 * 16 + 4 * sk + lk];
+        a0[4 + sk] = (zoff[sk] >= 0) ? Z[r0 * ZS + zoff[sk]] : 0.0;
+        a1[4 + sk] = (zoff[sk] >= 0) ? Z[r1 * ZS + zoff[sk]] : 0.0;
+      }
+      v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sk = 0; sk < 8; sk++) {
+        const double bv = sk < 4 ? bph[sk] : bdx[sk - 4];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[sk], bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[sk], bv, acc1, 0, 0, 0);
+      }
+      // (every lane of the wave has its operands before any lane stores: the stores depend on the MFMA results)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int row0 = 16 * t + lk + 4 * r4, row1 = 16 * t1 + lk + 4 * r4;
+        if (row0 < nf) Pbc[row0 * 16 + lr] = acc0[r4];
+        if (row1 < nf) Pbc[row1 * 16 + lr] = acc1[r4];
+      }
+    }
+  }
+  // body block  P_bb+ = T16 Phi_bb^T + Gs_b Gs_b^T + Qx : one 16 x 16 tile, 4 + 2 k-steps, on the first wave
+  if (tid < 64) {
+    const int lr = tid & 15, lk = tid >> 4;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sk = 0; sk < 4; sk++) {
+      const int k = 4 * sk + lk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T16[lr * 16 + k], S.PhibbT[k * 16 + lr], acc, 0, 0, 0);   // rows r = lr | cols c = lr
+    }
+#pragma unroll
+    for (int sk = 0; sk < 2; sk++) {
+      const int k = 4 * sk + lk;                                   // 0..7, the input-noise columns are k < 6
+      const double gv = (k < 6) ? Gdb[lr * 6 + k] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gv, gv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) {
+      const int r = lk + 4 * r4, c = lr;                           // a result lane holds column lr of rows lk + 4 r4
+      S.Mbb[r * 16 + c] = acc[r4] + ((r == c) ? a.Qx[r] : 0.0);    // P_bb+ staged in Mbb (T16 / Pbb are still being read)
+    }
+  }
 }
 
 // Store of P, cooperative part.  The workers scatter their 3x3 blocks (and the mirror images) into an LDS image of a chunk of
-// feature columns -- the X/Y region, free after the propagate; [column][n rows] -- and the whole workgroup streams the chunk
+// feature columns -- the Z region, free after the propagate; [column][n rows] -- and the whole workgroup streams the chunk
 // out with lanes along the rows: every wave instruction writes up to 512 contiguous bytes instead of 64 different cache
 // lines (the direct 8-byte block stores were bound by the texture path's one line per clock: 25 k clk per step).
 // Rows 0..15 of a feature column are the mirror of the LDS-resident body columns.
 struct StoreChunks {
   int fc, nchunks;   // features per chunk, number of chunks
-  __device__ StoreChunks(int N, int n, int nf) {
-    fc = max(1, min(N, (2 * nf * XK) / (3 * n)));
+  __device__ StoreChunks(int N, int n, int img_len) {
+    fc = max(1, min(N, img_len / (3 * n)));
     nchunks = (N + fc - 1) / fc;
   }
 };
@@ -400,7 +479,7 @@ template <int T>
 __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResShared& S, int f0, int f1, int tid) {
   const int n = S.n, ld = a.ld;
   double* P = a.P_out + (long)S.b * n * ld;
-  const double* img = S.X;
+  const double* img = S.Z;
   const int ncol = 3 * (f1 - f0), lane = tid & 63, w = tid >> 6;
   constexpr int NWV = T / 64;
   if ((n & 1) == 0) {   // even n: row pairs are 16-byte aligned in the image, in Pbc and in P (ld is even)
@@ -412,7 +491,7 @@ __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResSh
       for (int u = 0; u < 2; u++) {
         const int i = 2 * (lane + 64 * u);
         const double* src = (i < 16) ? (S.Pbc + (j - 16) * 16 + i) : (img + c * n + min(i, n - 2));
-        v[u] = *reinterpret_cast<const double2*>(src);
+        v[u] = lds_ld2(src);
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -440,34 +519,41 @@ __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResSh
 }
 
 template <int RB, int TW, bool MP>
-__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int TR, int TD, int tid) {
+__device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
   double* P = a.P + (long)S.b * n * ld;
   // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept, on wrapped diagonals
-  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: rows I >= N/2 of
-  //   it are left unowned).  Thread (tr, td) of a TR x TD grid owns rows I = tr + TR*a (a < RB) of diagonal d = td.
-  const int tr_ = tid % TR, td_ = tid / TR;
+  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: only its rows
+  //   I < N/2 are owned).  The N (N + 1) / 2 owned blocks are numbered  idx = d N + I  and dealt round-robin: thread t keeps
+  //   idx = t + TW a, a < RB  -- any thread count, RB = ceil(N (N + 1) / 2 / TW) blocks per thread, and the lanes of a wave
+  //   hold consecutive rows I of (mostly) one diagonal.  Slot a = 0 of the threads t < N is the diagonal d = 0.
+  const int tid_ = tid;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
   double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
   // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
-  const bool evenN = (N & 1) == 0;
-  auto blk = [&](int tr, int td, int ia, int& I, int& J) -> bool {   // block ia of thread (tr,td); false = not owned
-    I = tr + TR * ia;
-    const bool v = td < TD && I < N && !(evenN && td == N / 2 && I >= N / 2);
-    I = min(I, N - 1);                    // clamped: every LDS / global read stays in range, results never stored
-    J = I + min(td, TD - 1);
+  const int nown = N * (N + 1) / 2;
+  const float rcpN = 1.0f / (float)N;
+  auto blk = [&](int t, int ia, int& I, int& J) -> bool {   // block ia of thread t; false = not owned
+    int idx = t + TW * ia;
+    const bool v = idx < nown;
+    idx = min(idx, nown - 1);             // clamped: every LDS / global read stays in range, results never stored
+    const int d = (int)(((float)idx + 0.5f) * rcpN);   // idx / N (exact: idx < 2^20, the margin 0.5 / N dwarfs the rounding)
+    I = idx - d * N;
+    J = I + d;
     if (J >= N) J -= N;
     return v;
   };
+  const bool own_diag = tid_ < N;   // slot 0 of this thread is the diagonal block (I, I), I = tid
+  static_assert(TW >= 64, "the diagonal d = 0 must sit in slot 0: TW >= N");
 
   double pb[RB][9];   // pb[a][r*3+s] = P[16+3I+r][16+3J+s]
   {
-    const int tr = opaque(tr_), td = opaque(td_);
+    const int tq = opaque(tid_);
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
       int I, J;
-      blk(tr, td, ia, I, J);
+      blk(tq, ia, I, J);
       const double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);
 #pragma unroll
       for (int s = 0; s < 3; s++)
@@ -494,10 +580,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // only for symmetric P; on an antisymmetric part A it is  A_zz' = A_zz + K (Hb A_zz Hb^T) K^T  -- growth per update where
   // the Joseph form contracts -- and rounding-level asymmetry reaches 1e-7 within 3 s of flight (tests/test_sim_end_to_end.py).
   auto sym_diag = [&]() {
-    if (td_ == 0) {
-#pragma unroll
-      for (int ia = 0; ia < RB; ia++) { pb[ia][3] = pb[ia][1]; pb[ia][6] = pb[ia][2]; pb[ia][7] = pb[ia][5]; }
-    }
+    if (own_diag) { pb[0][3] = pb[0][1]; pb[0][6] = pb[0][2]; pb[0][7] = pb[0][5]; }
   };
   sym_diag();
   // Lambda for feature/feature blocks: one 3x3 constant (lambda_feat identical for all slots), kept in SGPRs
@@ -526,7 +609,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     // (the thread index is laundered per propagate: otherwise everything derived from it is hoisted out of this loop and
     //  kept alive across it -- spills)
     const int tk = MP ? opaque(tid) : tid;
-    double* X = S.X; double* Y = S.Y; double* phiff = S.phiff;
+    const double* Z = S.Z; double* phiff = S.phiff;
     res_prop_setup<TW>(a, S, tk);
     RES_STAMP(S, tid == 0, 66);
     __syncthreads();  // B3p
@@ -536,9 +619,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     //      first each row times Phi_ff[J]^T, then each column times Phi_ff[I]  (keeps the register peak low)
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
-      const int tr = opaque(tr_), td = opaque(td_);
+      const int tq = opaque(tid_);
       int I, J;
-      const bool v = blk(tr, td, ia, I, J);
+      const bool v = blk(tq, ia, I, J);
       const double* fj = phiff + 9 * J;
 #pragma unroll
       for (int r = 0; r < 3; r++) {
@@ -559,35 +642,44 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         pb[ia][8] += a.Qx[16 + 3 * I + 2];
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (RB > 4) {   // pin the block's new values here: their arithmetic is otherwise sunk towards its first use, with the
+                      // (twice as many) operands held live instead
+#pragma unroll
+        for (int e = 0; e < 9; e++) asm volatile("" : "+v"(pb[ia][e]));
+      }
+      group_fence<(RB > 4)>();
     }
     RES_STAMP(S, tid == 0, 68);
-    // ---- register-tiled contraction  P[I,J] += X_I Y_J^T  (K = 38)
-    // (Phi_fb has no POS columns -- nothing depends on the position, vi_ekf_dyn.cpp:55-71 -- so Y[.,0..1] and X[.,16..17] are
-    //  exactly zero: those two column pairs are skipped)
-#pragma unroll 1
-    for (int k = 2; k < XK; k += 2) {
-      if (k == 16) continue;
-      const int tr = opaque(tr_), td = opaque(td_);
+    // ---- register-tiled contraction  P[I,J] += Ut_I D_J^T + D_I Ut_J^T + Gs_I Gs_J^T  (K = 24): one 16-byte read per row
+    //      and k gives the pair (Ut[k], D[k]) -- or two adjacent columns of Gs
+    auto contract = [&](int k, auto crossed) {
+      constexpr bool CROSS = decltype(crossed)::value;
+      const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
         int I, J;
-        blk(tr, td, ia, I, J);
+        blk(tq, ia, I, J);
         double2 xv[3], yv[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) xv[r] = *reinterpret_cast<const double2*>(X + (3 * I + r) * XK + k);
+        for (int r = 0; r < 3; r++) xv[r] = lds_ld2(Z + (3 * I + r) * ZS + 2 * k);
 #pragma unroll
-        for (int s = 0; s < 3; s++) yv[s] = *reinterpret_cast<const double2*>(Y + (3 * J + s) * XK + k);
+        for (int s = 0; s < 3; s++) yv[s] = lds_ld2(Z + (3 * J + s) * ZS + 2 * k);
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
           for (int s = 0; s < 3; s++) {
             double acc = pb[ia][r * 3 + s];
-            acc = fma(xv[r].x, yv[s].x, acc);
-            acc = fma(xv[r].y, yv[s].y, acc);
+            acc = fma(xv[r].x, CROSS ? yv[s].y : yv[s].x, acc);   // Ut_I . D_J + D_I . Ut_J   |   Gs_I . Gs_J
+            acc = fma(xv[r].y, CROSS ? yv[s].x : yv[s].y, acc);
             pb[ia][r * 3 + s] = acc;
           }
+        if (ia & 1) group_fence<(RB > 4)>();   // (many blocks per thread: the operands of two in flight)
       }
-    }
+    };
+#pragma unroll 1
+    for (int k = 0; k < ZK; k++) contract(k, std::true_type{});
+#pragma unroll 1
+    for (int k = ZK; k < ZK + 3; k++) contract(k, std::false_type{});
     sym_diag();
     RES_STAMP(S, tid == 0, 69);
     if (MP) res_prop_body<TW>(a, S, tk);   // (single propagate: the service wave does this meanwhile, it would only wait)
@@ -595,17 +687,11 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
     for (int e = tk; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
-    if (MP && kp + 1 < nkp && td_ == 0 && S.sm[40 + (par ^ 1)] != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
-      const int mb = par ^ 1;
-#pragma unroll
-      for (int ia = 0; ia < RB; ia++) {
-        int I, J;
-        if (blk(tr_, td_, ia, I, J) && I < len) {
-          const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
-          if (ad != 0.0) { pb[ia][8] += ad; S.fixadd[mb * N + I] = 0.0; }
-          if (st != 0.0) { pb[ia][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
-        }
-      }
+    if (MP && kp + 1 < nkp && own_diag && tid_ < len && S.sm[40 + (par ^ 1)] != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
+      const int mb = par ^ 1, I = tid_;
+      const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
+      if (ad != 0.0) { pb[0][8] += ad; S.fixadd[mb * N + I] = 0.0; }
+      if (st != 0.0) { pb[0][8] = prm.P0_feat[2]; S.fixset[mb * N + I] = 0.0; }
     }
    }
 
@@ -613,26 +699,22 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   int Ib[RB], Jb[RB];
   bool vb[RB];
 #pragma unroll
-  for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tr_, td_, ia, Ib[ia], Jb[ia]);
+  for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tid_, ia, Ib[ia], Jb[ia]);
   const double p0rr = uniform_f64(prm.P0_feat[2]);   // (read here: a global load inside the update loop would put vmcnt waits there)
   // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
   auto apply_fixes = [&](int mb, double pending) {
     if (pending == 0.0) return;   // nothing posted (the common case); the flag word was read ahead of the barrier
-#pragma unroll
-    for (int ia = 0; ia < RB; ia++) {
-      const int I = Ib[ia];
-      if (vb[ia] && td_ == 0 && I < len) {
-        const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
-        if (ad != 0.0) { pb[ia][8] += ad; S.fixadd[mb * N + I] = 0.0; }
-        if (st != 0.0) { pb[ia][8] = p0rr; S.fixset[mb * N + I] = 0.0; }
-      }
+    if (own_diag && tid_ < len) {
+      const int I = tid_;
+      const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
+      if (ad != 0.0) { pb[0][8] += ad; S.fixadd[mb * N + I] = 0.0; }
+      if (st != 0.0) { pb[0][8] = p0rr; S.fixset[mb * N + I] = 0.0; }
     }
   };
   // Publishes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into Praw for the
   // service wave, which turns them into the gain rows: the pair {I, slot} is held either as block (I, slot) (its columns
   // 0,1) or, transposed, as block (slot, J = I) (its rows 0,1).
-  auto extract_cols = [&](int slot) {
-    double* Pw = S.Praw;
+  auto extract_cols = [&](int slot, double* Pw) {
 #pragma unroll
     for (int ia = 0; ia < RB; ia++) {
       const int I = Ib[ia], J = Jb[ia];
@@ -654,27 +736,28 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // ---------------- M sequential feature updates: covariance side ----------------
   int m = res_next_valid(S, 0);
   // hand the zeta-zeta 2x2 of every diagonal block to the service lanes (they keep it current from here on)
-#pragma unroll
-  for (int ia = 0; ia < RB; ia++)
-    if (vb[ia] && td_ == 0) {
-      *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia]) = make_double2(pb[ia][0], pb[ia][1]);
-      *reinterpret_cast<double2*>(S.Pd + 4 * Ib[ia] + 2) = make_double2(pb[ia][3], pb[ia][4]);
-    }
-  double* stash = S.Praw + 2 * n;   // [2][16][2]: rows j0, j0+1 x body columns of a LATER measurement's feature (see below)
+  if (own_diag) {
+    *reinterpret_cast<double2*>(S.Pd + 4 * tid_) = make_double2(pb[0][0], pb[0][1]);
+    *reinterpret_cast<double2*>(S.Pd + 4 * tid_ + 2) = make_double2(pb[0][3], pb[0][4]);
+  }
+  // Raw column pairs P[:, j0:j0+2] of a measured feature go to the service wave through two buffers [n][2] (Praw): the
+  // columns of measurement m+2 are published in phase m, as they stand after the sweep of measurement m; the service wave
+  // applies the one intervening update (m+1) to them itself when it forms the gain rows of m+2 -- so nothing it needs is
+  // produced inside its own phase: no hand-shake, no polling, and the publishing sits off every critical path.
   int2 sq = S.mseq[min(m, MCAP - 1)];
   if (m < S.M) {
     apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
     const int s0 = S.mslot[m];
-    extract_cols(s0);
-    // body rows of the first measurement's columns (P[k][j0+c] = P[j0+c][k]) and, for the service wave's phase 0, the same
-    // rows of the SECOND measurement's feature: 8 threads each, two body columns per thread
+    extract_cols(s0, S.Praw);                                   // first measurement: buffer 0
+    if (sq.y >= 0) extract_cols(sq.y, S.Praw + 2 * n);          // second one: buffer 1
+    // body rows of those columns (P[k][j0+c] = P[j0+c][k]): 8 threads each, two body columns per thread
     const int e = opaque(tid);
     if (e < 16) {
       const int sf = (e < 8) ? s0 : sq.y, ijj = (e & 7) * 2;
       if (sf >= 0) {
-        const double2 q0 = *reinterpret_cast<const double2*>(Pbc + (3 * sf) * 16 + ijj);
-        const double2 q1 = *reinterpret_cast<const double2*>(Pbc + (3 * sf + 1) * 16 + ijj);
-        double* d = (e < 8) ? (S.Praw + 2 * ijj) : (stash + 32 + 2 * ijj);
+        const double2 q0 = lds_ld2(Pbc + (3 * sf) * 16 + ijj);
+        const double2 q1 = lds_ld2(Pbc + (3 * sf + 1) * 16 + ijj);
+        double* d = S.Praw + ((e < 8) ? 0 : 2 * n) + 2 * ijj;
         *reinterpret_cast<double2*>(d) = make_double2(q0.x, q1.x);
         *reinterpret_cast<double2*>(d + 2) = make_double2(q0.y, q1.y);
       }
@@ -685,19 +768,18 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   __syncthreads();  // B1 : the service formed the first measurement's gain rows Kt / Wt, verdict and NaN word
   int it_ = 0;
   int cnt = 0;
-  // ONE barrier per update.  Inside a phase the worker waves (1) sweep their blocks with the gains of measurement m,
-  // (2) publish the next measurement's raw feature rows from the swept registers and count themselves in, (3) sweep the
-  // LDS-resident body columns.  The service wave runs the state chain of measurement m meanwhile, then -- once every
-  // worker wave is counted in -- turns the raw columns into the gain rows of measurement m+1, overlapping (3).  The raw BODY
-  // rows are not taken from (3) (that would put it before the count): the owner of the body-column item of the feature
-  // measured two phases later stashes its two rows, and the service applies the one intervening rank-2 update to them.
+  // ONE barrier per update, and no other hand-shake.  Inside a phase the worker waves (1) sweep their blocks with the gains
+  // of measurement m, (2) publish the raw feature rows of measurement m+2's columns from the swept registers, (3) sweep the
+  // LDS-resident body columns (the owner of the body-column item of that feature adds its body rows to the same buffer).
+  // The service wave runs the state chain of measurement m meanwhile and forms the gain rows of measurement m+1 from the
+  // columns published one phase earlier.
   while (m < S.M) {
-    const int mnext = sq.x, slot_next = sq.y;
+    const int mnext = sq.x;
     // gain rows {K [n][2], W [n][2]} are double-buffered: the service wave forms those of measurement m+1 while step (3) of
-    // this phase still reads those of measurement m.  The second buffer is the X region (free outside the propagate).
-    const double* kP = (cnt & 1) ? S.X : S.Kt;
+    // this phase still reads those of measurement m.  The second buffer is the Z region (free outside the propagate).
+    const double* kP = (cnt & 1) ? S.Z : S.Kt;
     const double* wP = kP + 2 * n;
-    __builtin_amdgcn_s_setprio(1);   // steps (1)-(2) are on the update's critical path, (3) is not
+    __builtin_amdgcn_s_setprio(1);
     const double fixpending = S.sm[40 + (par ^ 1)];   // posted before the barrier by the service wave
     const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
     const double nanw = S.sm[44 + cnt % 3];
@@ -705,36 +787,46 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
     const int it = tid;
-    double2 kI[RB][3], wJ[RB][3];
-#pragma unroll
-    for (int ia = 0; ia < RB; ia++) {
-#pragma unroll
-      for (int r = 0; r < 3; r++) kI[ia][r] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * Ib[ia] + r));
-#pragma unroll
-      for (int s = 0; s < 3; s++) wJ[ia][s] = *reinterpret_cast<const double2*>(wP + 2 * (16 + 3 * Jb[ia] + s));
-    }
-    apply_fixes(par ^ 1, fixpending);
+    // ---- (1) feature/feature blocks (registers).  The operand rows of GB blocks are in flight together: all of them with
+    //      few blocks per thread; two at a time with many, where holding every block's rows would not fit the register file
+    constexpr int GB = (RB <= 4) ? RB : 2;
     const bool gated = gflag != 0.0;
     const bool run = !gated && nanw == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
-    if (run) {
-      // ---- (1) feature/feature blocks (registers)
+    bool fixed = false;
 #pragma unroll
-      for (int ia = 0; ia < RB; ia++)
+    for (int g0 = 0; g0 < RB; g0 += GB) {
+      double2 kI[GB][3], wJ[GB][3];
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+      for (int ig = 0; ig < GB; ig++) {
+        const int ia = (g0 + ig < RB) ? g0 + ig : RB - 1;
 #pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const double t = fma(kI[ia][r].y, wJ[ia][s].y, kI[ia][r].x * wJ[ia][s].x);
-            pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
-          }
+        for (int r = 0; r < 3; r++) kI[ig][r] = lds_ld2(kP + 2 * (16 + 3 * Ib[ia] + r));
+#pragma unroll
+        for (int s = 0; s < 3; s++) wJ[ig][s] = lds_ld2(wP + 2 * (16 + 3 * Jb[ia] + s));
+      }
+      if (!fixed) { apply_fixes(par ^ 1, fixpending); fixed = true; }
+      if (run) {
+#pragma unroll
+        for (int ig = 0; ig < GB; ig++) {
+          if (g0 + ig >= RB) continue;
+          const int ia = g0 + ig;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+              const double t = fma(kI[ig][r].y, wJ[ig][s].y, kI[ig][r].x * wJ[ig][s].x);
+              pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
+            }
+        }
+      }
+      group_fence<(RB > GB)>();
     }
     sym_diag();
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
-    // ---- (2) the NEXT measurement's raw feature rows (a fix_depth edit touches P(rho,rho) only, never these columns)
-    if (slot_next >= 0 && !(S.dbg & 4)) extract_cols(slot_next);
-    asm volatile("" ::: "memory");   // (LDS executes a wave's accesses in order: the count lands after the stores above)
-    if ((tid & 63) == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(S.sm + 49), 1, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ---- (2) the raw feature rows of the measurement after next (a fix_depth edit touches P(rho,rho) only, never these
+    //      columns), into the buffer the service wave is not reading in this phase
+    double* rawdst = S.Praw + (cnt & 1) * 2 * n;
+    if (sq.y >= 0 && !(S.dbg & 4)) extract_cols(sq.y, rawdst);
     __builtin_amdgcn_s_setprio(0);
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -745,14 +837,14 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       const int g = item >> 3, j2 = (item & 7) * 2;
       double2 cpv[3];
 #pragma unroll
-      for (int q = 0; q < 3; q++) cpv[q] = *reinterpret_cast<const double2*>(Pbc + (3 * g + q) * 16 + j2);
+      for (int q = 0; q < 3; q++) cpv[q] = lds_ld2(Pbc + (3 * g + q) * 16 + j2);
       if (run) {
-        const double2 cw0 = *reinterpret_cast<const double2*>(wP + 2 * j2);
-        const double2 cw1 = *reinterpret_cast<const double2*>(wP + 2 * j2 + 2);
-        const double2 clk = *reinterpret_cast<const double2*>(S.lam + j2);
+        const double2 cw0 = lds_ld2(wP + 2 * j2);
+        const double2 cw1 = lds_ld2(wP + 2 * j2 + 2);
+        const double2 clk = lds_ld2(S.lam + j2);
         double2 cki[3];
 #pragma unroll
-        for (int q = 0; q < 3; q++) cki[q] = *reinterpret_cast<const double2*>(kP + 2 * (16 + 3 * g + q));
+        for (int q = 0; q < 3; q++) cki[q] = lds_ld2(kP + 2 * (16 + 3 * g + q));
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           const double L0 = partial ? (clk.x + lfe[q] - lfe[q] * clk.x) : 1.0;
@@ -764,7 +856,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       }
       // rows j0, j0+1 of the feature measured two phases from now, as they stand after this phase's sweep
       if (g == sq.y) {
-        double* st = stash + 32 * (cnt & 1) + 2 * j2;
+        double* st = rawdst + 2 * j2;
         *reinterpret_cast<double2*>(st) = make_double2(cpv[0].x, cpv[1].x);
         *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
       }
@@ -777,10 +869,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         const int br = ib >> 3, bc2 = (ib & 7) * 2;
         double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
         const double blr = S.lam[br];
-        const double2 blc = *reinterpret_cast<const double2*>(S.lam + bc2);
-        const double2 kr = *reinterpret_cast<const double2*>(kP + 2 * br), wr = *reinterpret_cast<const double2*>(wP + 2 * br);
-        const double2 k0 = *reinterpret_cast<const double2*>(kP + 2 * bc2), w0 = *reinterpret_cast<const double2*>(wP + 2 * bc2);
-        const double2 k1 = *reinterpret_cast<const double2*>(kP + 2 * bc2 + 2), w1 = *reinterpret_cast<const double2*>(wP + 2 * bc2 + 2);
+        const double2 blc = lds_ld2(S.lam + bc2);
+        const double2 kr = lds_ld2(kP + 2 * br), wr = lds_ld2(wP + 2 * br);
+        const double2 k0 = lds_ld2(kP + 2 * bc2), w0 = lds_ld2(wP + 2 * bc2);
+        const double2 k1 = lds_ld2(kP + 2 * bc2 + 2), w1 = lds_ld2(wP + 2 * bc2 + 2);
         const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
         const bool up0 = br <= bc2, up1 = br <= bc2 + 1;
         const double2 ka = up0 ? kr : k0, wa = up0 ? w0 : wr;      // (K_lo, W_hi) of element (br, bc2)
@@ -813,17 +905,17 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];
     }
     for (int e = opaque(tid); e < 256; e += TW) P[(e >> 4) + (long)(e & 15) * ld] = Pbb[e];
-    const StoreChunks sc(N, n, nf);
-    double* img = S.X;
+    const StoreChunks sc(N, n, S.img_len);
+    double* img = S.Z;
     const int gtid = threadIdx.x;
     RES_STAMP(S, tid == 0, 224);
     for (int ch = 0; ch < sc.nchunks; ch++) {
       const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
-      const int tr = opaque(tr_), td = opaque(td_);
+      const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
         int I, J;
-        if (blk(tr, td, ia, I, J)) {
+        if (blk(tq, ia, I, J)) {
           if (J >= f0 && J < f1) {                          // block (I,J): columns of feature J
             double* d = img + (3 * (J - f0)) * n + 16 + 3 * I;
 #pragma unroll
@@ -870,19 +962,29 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // The dynamics of the propagate need only the state (in LDS since the prologue): they run BEFORE B0, while the worker
   // waves are still loading P from HBM, instead of holding every worker up afterwards.
   double dt = sm[42];
-  // dynamics of propagate kp (of S.kp): body Jacobian on lane 0, one feature per lane
-  auto dynamics = [&](int kp, double dtk, double* phiff_dst) {
+  // dynamics of propagate kp (of S.kp): body Jacobian on lane 0 (+ A_v G_b for the workers' expansion of the feature rows),
+  // then one feature per lane
+  auto dyn_body = [&](int kp) {
     for (int i = lane; i < 256; i += 64) S.Abb[i] = 0.0;
     for (int i = lane; i < 96; i += 64) S.Gb[i] = 0.0;
     if (lane < 16) S.xdb[lane] = 0.0;
     if (lane == 0) res_body_phase(xs, u_all + ((long)kp * S.B + S.b) * 6, a.dp, S.ctx, S.xdb, S.Abb, S.Gb);
     RES_STAMP(S, lane == 0 && kp == 0, 2);
-    // (same wave: the LDS accesses of lane 0 above are complete before the feature lanes read ctx)
+    // (same wave: the LDS accesses of lane 0 above are complete before the other lanes read ctx / A_bb / G_b)
     wave_lds_sync();
-    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dtk, xs, S.ctx, S.featA, phiff_dst);
-    RES_STAMP(S, lane == 0 && kp == 0, 4);
+    if (lane >= 64 - 18) {   // A_v G_b (3 x 6), one entry per lane, on lanes that carry no feature
+      const int e = lane - (64 - 18), j = e / 6, k = e - 6 * j;
+      double sv = 0.0;
+#pragma unroll 4
+      for (int c = 0; c < 16; c++) sv += S.Abb[(dxVEL + j) * 16 + c] * S.Gb[c * 6 + k];
+      S.AvG[e] = sv;
+    }
   };
-  if (S.do_prop) dynamics(0, dt, S.phiff);
+  auto dyn_feat = [&](double dtk) {
+    for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dtk, xs, S.ctx, S.Z, S.phiff);
+    RES_STAMP(S, lane == 0, 4);
+  };
+  if (S.do_prop) { dyn_body(0); dyn_feat(dt); }
   __syncthreads();  // B0
   RES_STAMP(S, lane == 0, 1);
 
@@ -892,7 +994,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     __syncthreads();  // B1p
     RES_STAMP(S, lane == 0, 3);
     __syncthreads();  // B2p
-    __syncthreads();  // B2q (workers expand featA into the Phi_fb rows)
+    __syncthreads();  // B2q
     RES_STAMP(S, lane == 0, 5);
     if (lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
       double dxb[16], xo[17];
@@ -909,24 +1011,24 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     RES_STAMP(S, lane == 0, 6);
     __syncthreads();  // B3p
     RES_STAMP(S, lane == 0, 7);
-    // Several propagates per launch: the NEXT one's dynamics run here, under the workers' contraction (this wave would
-    // only wait for B4p).  The state they need is final (body step and fix_depth above); of their outputs the workers still
-    // read Phi_ff (local transforms) -- the new blocks go to the idle gain-row buffer and are copied over after B4p --,
-    // nothing else (featA, A_bb, G_b were consumed before B3p; dt is read after B1p).
+    // Several propagates per launch: the body part of the NEXT one's dynamics runs here, under the workers' contraction (this
+    // wave would only wait for B4p).  The body state it needs is final (body step above) and nothing it writes (A_bb, G_b,
+    // A_v G_b, xdot, ctx) is read again before the next B1p; the feature part writes Z rows and Phi_ff, which the workers
+    // are still reading: it runs after B4p.
     double dt_next = 0.0;
     if (MP && kp + 1 < nkp) {
       dt_next = dt_all[(long)(kp + 1) * S.B + S.b];
-      dynamics(kp + 1, dt_next, S.Kt);
+      dyn_body(kp + 1);
     }
-    // One propagate per launch: this wave takes the body strips and the body block of P+ (res_prop_body: they need U, ready
-    // since B3p, and write what no contraction reads) off the workers' path instead of waiting for them.
+    // One propagate per launch: this wave takes the body strips and the body block of P+ (res_prop_body: they need V, D, Xi,
+    // ready since B3p, and write what no contraction reads) off the workers' path instead of waiting for them.
     if (!MP) res_prop_body<64>(a, S, lane);
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
     if (MP && kp + 1 < nkp) {
-      for (int i = lane; i < 9 * N; i += 64) S.phiff[i] = S.Kt[i];
       dt = dt_next;
       if (lane == 0) sm[42] = dt;
+      dyn_feat(dt);
     }
    }
 
@@ -975,7 +1077,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   auto predict = [&](const double* t1, const double* t2, const double* zt, int mm, int src, Meas& o) {
     double zhat[2], Hb[4], Sm[4], Si[4];
     h_feat_frame(t1, t2, zt, prm, zhat, Hb);
-    const double2 zn = *reinterpret_cast<const double2*>(S.mz + 2 * mm);
+    const double2 zn = lds_ld2(S.mz + 2 * mm);
     const double* R = S.mR + 4 * mm;
     const double r0 = zn.x - zhat[0], r1 = zn.y - zhat[1];
     const double w00 = pf00 * Hb[0] + pf01 * Hb[1], w01 = pf00 * Hb[2] + pf01 * Hb[3];   // (P_zz Hb^T)
@@ -999,27 +1101,18 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   double f1[3], f2[3], fz[3];
   bearing_frame_fast(qn, f1, f2, fz);
   const double sgn = isatt ? -1.0 : 1.0;   // q (x) e instead of e (x) q flips the cross term only
-  // Gain rows of the measurement whose mailbox is `mb`, for ALL n rows (three per lane), from the raw columns:
+  // Gain rows of a measurement for ALL n rows (three per lane) from its raw column pair pr (this lane's rows):
   //   W_i = P[i, j0:j0+2] Hb^T,  K_i = W_i S^-1   (vi_ekf_meas.cpp:241).
-  // Feature rows come from Praw (published by the worker waves); the 16 body rows either from Praw as well (first
-  // measurement) or from the two stashed rows of that feature, brought up to date with the rank-2 update that has been
-  // swept since (`swept`, gains still in Kt / Wt; `slot` = the feature, `sb` = stash buffer).
   // Also leaves the NaN guard (:247; a NaN in H makes every K row NaN, so testing K covers the H test) and the gate verdict
   // for the workers' next phase.
-  const double* stash = S.Praw + 2 * n;
   const double lraw[3] = {S.lam[rid0], S.lam[rid1], S.lam[rid2]};
   // The rows are dealt by ROLE (a feature lane its three rows, the attitude lane rows 6..8, a linear body lane its one row),
   // so a lane's own rows of K and W -- all that its state correction needs in the next phase -- stay in registers.
   struct Rows { double2 kA, wA, kB, wB, kC; int bad; };
   const bool three = isfeat || isatt;   // lanes with three distinct rows (the others would write the same row three times)
   const int ridv[3] = {rid0, rid1, rid2};
-  auto gain_rows = [&](const Meas& q, int nanword, int gateword, bool from_stash, const double2 (&stb)[3], double* Kd,
-                       Rows& o) {
+  auto gain_rows = [&](const Meas& q, int nanword, int gateword, const double2 (&pr)[3], double* Kd, Rows& o) {
     double* Wd = Kd + 2 * n;                             // (Kd: destination buffer)
-    double2 pr[3];
-#pragma unroll
-    for (int u = 0; u < 3; u++) pr[u] = *reinterpret_cast<const double2*>(S.Praw + 2 * ridv[u]);
-    if (from_stash && !isfeat) { pr[0] = stb[0]; pr[1] = stb[1]; pr[2] = stb[2]; }
     int bad = 0;
     double2 wv[3], kv[3];
 #pragma unroll
@@ -1037,55 +1130,65 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     if (lane == 0) { sm[nanword] = bad ? 1.0 : 0.0; sm[gateword] = q.gate; }
     o.kA = kv[0]; o.wA = wv[0]; o.kB = kv[1]; o.wB = wv[1]; o.kC = kv[2]; o.bad = bad;
   };
-  // The 16 body rows of the NEXT measurement's columns come from the two stashed rows of that feature (see the worker side),
-  // brought up to date with the rank-2 update being swept in this phase (gains Kc / Wc, `swept` = it is applied).  Everything
-  // this needs is complete at the top of a phase, so it runs there, off the critical path.  (Feature lanes discard it.)
-  auto stash_rows = [&](int sb, bool swept, int slot, const double* Kc, double2 (&o)[3]) {
+  // This lane's rows of the NEXT measurement's column pair: published by the worker waves one phase ago (buffer `rb`), as they
+  // stood BEFORE the update being swept in this phase -- which is applied here (`swept`; gains Kc / Wc, this lane's own K rows
+  // k3), with the workers' expression  p - Lambda (K . W):  feature rows i take K_i (own) and W of the column's feature,
+  // body rows k take K of the column's feature and W_k, as the block sweep and the body-column sweep do.  Everything this
+  // needs is complete at the top of a phase, so it runs there, off the critical path.
+  const double lfz[3] = {a.lambda[16], a.lambda[17], a.lambda[18]};
+  auto next_rows = [&](int rb, bool swept, int slot, const double* Kc, const double2 (&k3)[3], double2 (&o)[3]) {
+    const double* raw = S.Praw + rb * 2 * n;
     const double* Wc = Kc + 2 * n;
-    const double2 ka = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot));
-    const double2 kb2 = *reinterpret_cast<const double2*>(Kc + 2 * (16 + 3 * slot + 1));
+    const double2 ka = lds_ld2(Kc + 2 * (16 + 3 * slot)), kb2 = lds_ld2(Kc + 2 * (16 + 3 * slot + 1));
+    const double2 wa = lds_ld2(Wc + 2 * (16 + 3 * slot)), wb2 = lds_ld2(Wc + 2 * (16 + 3 * slot + 1));
     auto one = [&](int u) {
-      const int k = isfeat ? 0 : ridv[u];
-      const double2 st = *reinterpret_cast<const double2*>(stash + 32 * sb + 2 * k);   // (P[j0][k], P[j0+1][k]) before ...
-      // ... the update with gains K, W -- the same expression, operand for operand, as the workers' body-column sweep
-      const double2 wk = *reinterpret_cast<const double2*>(Wc + 2 * k);
-      const double lamk = lraw[u];
+      const double2 st = lds_ld2(raw + 2 * ridv[u]);      // (P[i][j0], P[i][j0+1]) before the update
       double r0 = st.x, r1 = st.y;
       if (swept) {
+        const double lamk = isfeat ? lfz[u] : lraw[u];
         const double La = partial ? (lamk + lz0 - lz0 * lamk) : 1.0, Lb = partial ? (lamk + lz1 - lz1 * lamk) : 1.0;
-        r0 = fma(-La, fma(ka.y, wk.y, ka.x * wk.x), r0);
-        r1 = fma(-Lb, fma(kb2.y, wk.y, kb2.x * wk.x), r1);
+        const double2 wk = lds_ld2(Wc + 2 * ridv[u]);
+        // (operands by role, no divergence: K_i . W_j0 | K_j0 . W_k)
+        const double2 xa = isfeat ? k3[u] : ka, ya = isfeat ? wa : wk;
+        const double2 xb = isfeat ? k3[u] : kb2, yb = isfeat ? wb2 : wk;
+        r0 = fma(-La, fma(xa.y, ya.y, xa.x * ya.x), r0);
+        r1 = fma(-Lb, fma(xb.y, yb.y, xb.x * yb.x), r1);
       }
       o[u] = make_double2(r0, r1);
     };
     one(0);
-    if (isatt) { one(1); one(2); }   // (only the attitude lane has three distinct body rows)
+    if (three) { one(1); one(2); }
+    else { o[1] = o[0]; o[2] = o[0]; }
+    if (lane == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
   };
   Meas cur = {}, nxt = {};
   Rows crow = {}, nrow = {};
   if (m < M) {
     predict(f1, f2, fz, m, __builtin_amdgcn_readfirstlane(S.mslot[m]), cur);
-    const double2 none[3] = {};
-    gain_rows(cur, 44, 50, false, none, S.Kt, crow);   // (the first raw columns were published before Bp)
+    double2 pr0[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) pr0[u] = lds_ld2(S.Praw + 2 * ridv[u]);   // (the first raw columns: buffer 0, published before Bp)
+    gain_rows(cur, 44, 50, pr0, S.Kt, crow);
   }
   int2 sq = S.mseq[min(m, MCAP - 1)];
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
   int it_ = 0, cnt = 0;
-  lds_vint_t* rawcnt = (lds_vint_t*)(sm + 49);   // worker waves that have published the next raw columns (explicit LDS
-                                                 // pointer: a volatile access through the generic one becomes a FLAT load)
 
   while (m < M) {
     const int mnext = sq.x, slot_next = sq.y;
     // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
-    const double* kP = (cnt & 1) ? S.X : S.Kt;   // (double-buffered, see the worker side)
+    const double* kP = (cnt & 1) ? S.Z : S.Kt;   // (double-buffered, see the worker side)
     const double2 kA = crow.kA, wA = crow.wA, kB = crow.kB, wB = crow.wB, kC = crow.kC;   // (own rows: from registers)
     sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
     const bool gated = cur.gate != 0.0;
     const bool bad = crow.bad != 0;      // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows
     const double r0 = cur.r0, r1 = cur.r1;
-    double2 stb[3] = {};
-    if (slot_next >= 0) stash_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), slot_next, kP, stb);
+    double2 prn[3] = {};
+    if (slot_next >= 0) {
+      const double2 k3[3] = {kA, kB, kC};
+      next_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), slot_next, kP, k3, prn);
+    }
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
     const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
@@ -1146,16 +1249,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     if (slot_next >= 0) predict(f1, f2, fz, mnext, __builtin_amdgcn_readfirstlane(slot_next), nxt);   // next measurement, from registers
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
-    if (slot_next >= 0) {
-      // The worker waves publish the next raw feature rows right after their block sweeps, long before this point; the count
-      // is polled (never a barrier): the workers wait for this wave only at the barrier below, so the wait cannot deadlock.
-      int spins = 0;
-      while (*rawcnt < nww * (cnt + 1) && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); spins++; }
-      if (spins >= (1 << 22)) flag |= FLAG_INTERNAL;   // (never seen; a bounded wait that gives up must say so)
-      RES_STAMP(S, lane == 0 && it_ < 8, 48 + it_);
-      wave_lds_sync();   // the raw columns were written by other waves (count above)
-      gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), true, stb, (cnt & 1) ? S.Kt : S.X, nrow);
-    }
+    if (slot_next >= 0) gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), prn, (cnt & 1) ? S.Kt : S.Z, nrow);
     cur = nxt;
     crow = nrow;
     par ^= 1;
@@ -1184,7 +1278,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   if (flag) atomicOr(&a.flags[S.b], flag);
   RES_STAMP(S, lane == 0, 13);
   {   // cooperative store of P (see res_store_chunk): this wave streams its share of every chunk
-    const StoreChunks sc(N, n, S.nf);
+    const StoreChunks sc(N, n, S.img_len);
     for (int ch = 0; ch < sc.nchunks; ch++) {
       const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
       __syncthreads();   // S1
@@ -1205,9 +1299,9 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   const int b = blockIdx.x, tid = threadIdx.x;
   const ResLds L(a.N, a.n, a.nxs);
   S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
-  S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.X = smem + L.X; S.Y = smem + L.Y;
+  S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.Z = smem + L.Z; S.img_len = L.img_len;
   S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
-  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.featA = smem + L.featA;
+  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.PsiP = smem + L.PsiP; S.Pi = smem + L.Pi; S.Xi = smem + L.Xi; S.AvG = smem + L.AvG;
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
@@ -1264,7 +1358,7 @@ __global__ __launch_bounds__((NW + 1) * 64, (NW <= 3) ? 2 : 1) void k_step_resid
   constexpr int SVC = (NW == 6) ? 3 : NW;
   const int wave = tid >> 6;
   if (wave == SVC) res_service<T, MP>(a, S, tid & 63, NW, u_all, dt_all, result_all);
-  else res_worker<RB, TW, MP>(a, S, TR, TD, tid - (wave > SVC ? 64 : 0));
+  else res_worker<RB, TW, MP>(a, S, tid - (wave > SVC ? 64 : 0));
 }
 
 }  // namespace viekf
