@@ -35,7 +35,7 @@ constexpr int ZK = 9;    // rank of the feature/body coupling
 constexpr int ZS = 26;   // row stride of Z: 6 ZS = 28 (mod 64 dwords), consecutive features land on distinct 16-byte bank groups
 
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, PsiP, Pi, Xi, AvG, mslot, mseq, mz, mR, img_len, total;
+  int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, PsiP, Pi, Xi, AvG, Lbc, mslot, mseq, mz, mR, img_len, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
     const int nf = 3 * N;
     int o = 0;
@@ -64,6 +64,7 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     xdb = take(16);
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
     Pbc = take(nf * 16);
+    Lbc = take(48);   // Lambda of (feature row q, body column k): [3][16]
     mslot = take(32); mseq = take(64); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
     total = o;
   }
@@ -246,7 +247,7 @@ typedef __attribute__((address_space(3))) volatile int lds_vint_t;
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *Z, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
-      *xdb, *Pbc, *PhibbT, *Pd, *PsiP, *Pi, *Xi, *AvG, *mz, *mR;
+      *xdb, *Pbc, *PhibbT, *Pd, *PsiP, *Pi, *Xi, *AvG, *Lbc, *mz, *mR;
   int* mslot;   // [MCAP] slot, or -1 for a measurement that is not run
   int2* mseq;   // [MCAP] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
@@ -518,6 +519,45 @@ __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResSh
   }
 }
 
+// Body columns of an update, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements),
+// items [first, last) strided over `nthreads` callers; the mask Lambda of a (feature row, body column) pair comes from the
+// table Lbc [3][16] (prologue).  The owner of the item of the feature measured two phases from now also adds its rows -- as
+// they stand after this sweep -- to the raw column buffer `rawdst` (see res_worker).
+__device__ __forceinline__ void res_body_items(const ResShared& S, const double* kP, bool run, int id, int nthreads,
+                                               int first, int last, int slot2, double* rawdst) {
+  const double* wP = kP + 2 * S.n;
+  double* Pbc = S.Pbc;
+#pragma unroll 1
+  for (int item = first + id; item < last; item += nthreads) {
+    const int g = item >> 3, j2 = (item & 7) * 2;
+    double2 cpv[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) cpv[q] = lds_ld2(Pbc + (3 * g + q) * 16 + j2);
+    if (run) {
+      const double2 cw0 = lds_ld2(wP + 2 * j2);
+      const double2 cw1 = lds_ld2(wP + 2 * j2 + 2);
+      double2 cki[3], cl[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { cki[q] = lds_ld2(kP + 2 * (16 + 3 * g + q)); cl[q] = lds_ld2(S.Lbc + 16 * q + j2); }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        cpv[q].x = fma(-cl[q].x, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
+        cpv[q].y = fma(-cl[q].y, fma(cki[q].y, cw1.y, cki[q].x * cw1.x), cpv[q].y);
+        *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
+      }
+    }
+    // rows j0, j0+1 of the feature measured two phases from now, as they stand after this phase's sweep
+    if (g == slot2) {
+      double* st = rawdst + 2 * j2;
+      *reinterpret_cast<double2*>(st) = make_double2(cpv[0].x, cpv[1].x);
+      *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
+    }
+  }
+}
+// how many of the 8 N body-column items of an update the service wave sweeps (after its chain), by worker-wave count
+template <int NWV>
+__device__ __forceinline__ int res_service_items(int N) { return (NWV <= 3) ? min(8 * N, 128) : 0; }
+
 template <int RB, int TW, bool MP>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
@@ -528,6 +568,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   //   idx = t + TW a, a < RB  -- any thread count, RB = ceil(N (N + 1) / 2 / TW) blocks per thread, and the lanes of a wave
   //   hold consecutive rows I of (mostly) one diagonal.  Slot a = 0 of the threads t < N is the diagonal d = 0.
   const int tid_ = tid;
+  constexpr int NWV = TW / 64;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
   double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
@@ -592,7 +633,6 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 #pragma unroll
       for (int s = 0; s < 3; s++) Lff[r * 3 + s] = uniform_f64(prm.use_partial_update ? (lf[s] + lf[r] - lf[r] * lf[s]) : 1.0);
   }
-  const double lfe[3] = {uniform_f64(a.lambda[16]), uniform_f64(a.lambda[17]), uniform_f64(a.lambda[18])};
   const bool partial = prm.use_partial_update != 0;
   int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
   RES_STAMP(S, tid == 0, 64);
@@ -652,18 +692,38 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0, 68);
     // ---- register-tiled contraction  P[I,J] += Ut_I D_J^T + D_I Ut_J^T + Gs_I Gs_J^T  (K = 24): one 16-byte read per row
     //      and k gives the pair (Ut[k], D[k]) -- or two adjacent columns of Gs
-    auto contract = [&](int k, auto crossed) {
-      constexpr bool CROSS = decltype(crossed)::value;
+    // (many blocks per thread: the Z-row offsets of a block's I and J are packed into one register per block ahead of the
+    //  loop -- re-deriving them from the thread index cost as many instructions per k as the arithmetic)
+    int zoff[RB > 4 ? RB : 1];
+    if (RB > 4) {
       const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
         int I, J;
         blk(tq, ia, I, J);
+        zoff[ia] = (3 * I * ZS) | ((3 * J * ZS) << 16);
+      }
+    }
+    auto contract = [&](int k, auto crossed) {
+      constexpr bool CROSS = decltype(crossed)::value;
+      const int tq = opaque(tid_);
+#pragma unroll
+      for (int ia = 0; ia < RB; ia++) {
+        const double *zi, *zj;
+        if (RB > 4) {
+          zi = Z + (zoff[ia] & 0xffff) + 2 * k;
+          zj = Z + (zoff[ia] >> 16) + 2 * k;
+        } else {
+          int I, J;
+          blk(tq, ia, I, J);
+          zi = Z + (3 * I) * ZS + 2 * k;
+          zj = Z + (3 * J) * ZS + 2 * k;
+        }
         double2 xv[3], yv[3];
 #pragma unroll
-        for (int r = 0; r < 3; r++) xv[r] = lds_ld2(Z + (3 * I + r) * ZS + 2 * k);
+        for (int r = 0; r < 3; r++) xv[r] = lds_ld2(zi + r * ZS);
 #pragma unroll
-        for (int s = 0; s < 3; s++) yv[s] = lds_ld2(Z + (3 * J + s) * ZS + 2 * k);
+        for (int s = 0; s < 3; s++) yv[s] = lds_ld2(zj + s * ZS);
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -722,7 +782,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       const bool ascol = !asrow && I == slot;   // block (slot, J): its rows 0,1, transposed
       if (vb[ia] && (asrow || ascol)) {
         const int base = 16 + 3 * (asrow ? I : J);
-        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch)
+        // plain selects on compile-time register indices (a data-dependent index would push the block to scratch; so did
+        // select-free 8-byte stores of the two orientations, measured with 7 blocks per thread)
         const double a0 = pb[ia][0], a1 = asrow ? pb[ia][1] : pb[ia][3];
         const double b0 = asrow ? pb[ia][3] : pb[ia][1], b1 = pb[ia][4];
         const double c0 = asrow ? pb[ia][6] : pb[ia][2], c1 = asrow ? pb[ia][7] : pb[ia][5];
@@ -830,37 +891,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     __builtin_amdgcn_s_setprio(0);
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- (3) body columns, in LDS: item = (feature g, k pair j) = the 3 rows of one feature x 2 body columns (6 elements):
-    //      8 N items over the worker threads; the row lambdas are the lambda_feat constants, no per-row loads.
-#pragma unroll 1
-    for (int item = it; item < 8 * N; item += TW) {
-      const int g = item >> 3, j2 = (item & 7) * 2;
-      double2 cpv[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) cpv[q] = lds_ld2(Pbc + (3 * g + q) * 16 + j2);
-      if (run) {
-        const double2 cw0 = lds_ld2(wP + 2 * j2);
-        const double2 cw1 = lds_ld2(wP + 2 * j2 + 2);
-        const double2 clk = lds_ld2(S.lam + j2);
-        double2 cki[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) cki[q] = lds_ld2(kP + 2 * (16 + 3 * g + q));
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const double L0 = partial ? (clk.x + lfe[q] - lfe[q] * clk.x) : 1.0;
-          const double L1 = partial ? (clk.y + lfe[q] - lfe[q] * clk.y) : 1.0;
-          cpv[q].x = fma(-L0, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
-          cpv[q].y = fma(-L1, fma(cki[q].y, cw1.y, cki[q].x * cw1.x), cpv[q].y);
-          *reinterpret_cast<double2*>(Pbc + (3 * g + q) * 16 + j2) = cpv[q];
-        }
-      }
-      // rows j0, j0+1 of the feature measured two phases from now, as they stand after this phase's sweep
-      if (g == sq.y) {
-        double* st = rawdst + 2 * j2;
-        *reinterpret_cast<double2*>(st) = make_double2(cpv[0].x, cpv[1].x);
-        *reinterpret_cast<double2*>(st + 2) = make_double2(cpv[0].y, cpv[1].y);
-      }
-    }
+    // ---- (3) body columns, in LDS (res_body_items); with few worker waves the tail of the items is the service wave's: it
+    //      would only wait at the barrier, the workers are the longer side there
+    res_body_items(S, kP, run, it, TW, 0, 8 * N - res_service_items<NWV>(N), sq.y, rawdst);
     if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads.  Element (r, c) and its mirror (c, r) are
                  // owned by different threads; both form  p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own
                  // (equal) copies, so the block stays exactly symmetric without any exchange.
@@ -1250,6 +1283,11 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
     if (slot_next >= 0) gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), prn, (cnt & 1) ? S.Kt : S.Z, nrow);
+    {   // this wave's share of the body-column sweep of measurement m (few worker waves only), after its chain
+      constexpr int NWV = T / 64 - 1;
+      const int ns = res_service_items<NWV>(N);
+      if (ns > 0) res_body_items(S, kP, !gated && !bad && !(S.dbg & 1), lane, 64, 8 * N - ns, 8 * N, sq.y, S.Praw + (cnt & 1) * 2 * n);
+    }
     cur = nxt;
     crow = nrow;
     par ^= 1;
@@ -1301,7 +1339,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   S.xs = smem + L.xs; S.Kt = smem + L.Kt; S.Wt = smem + L.Wt; S.Praw = smem + L.Praw; S.lam = smem + L.lam;
   S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset; S.Z = smem + L.Z; S.img_len = L.img_len;
   S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
-  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.PsiP = smem + L.PsiP; S.Pi = smem + L.Pi; S.Xi = smem + L.Xi; S.AvG = smem + L.AvG;
+  S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT; S.Pd = smem + L.Pd; S.PsiP = smem + L.PsiP; S.Pi = smem + L.Pi; S.Xi = smem + L.Xi; S.AvG = smem + L.AvG; S.Lbc = smem + L.Lbc;
   S.mz = smem + L.mz; S.mR = smem + L.mR;
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
@@ -1312,6 +1350,10 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
+    if (tid < 48) {
+      const double lk = a.lambda[tid & 15], lq = a.lambda[16 + (tid >> 4)];
+      S.Lbc[tid] = a.dp->use_partial_update ? (lk + lq - lq * lk) : 1.0;
+    }
     if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
