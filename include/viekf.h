@@ -154,8 +154,8 @@ int viekf_batch_keep_features(viekf_batch *b, const uint8_t *keep, int32_t *new_
 /* Keyframe reset (VIEKF::keyframe_reset, src/vi_ekf/vi_ekf_kfr.cpp:56-157): position <- 0, yaw <- 0, P <- N P N^T.
  * mask [batch] (NULL = every filter): which filters reset (the overlap test of keep_only_features, vi_ekf_feat.cpp:99-104,
  * is the caller's).  edge [batch][17] (may be NULL): the relative pose that the reference folds into its global node frame,
- * {t(3), q_yaw(4; w,x,y,z), cov_pos(9, column-major 3x3), cov_yaw}; the composition itself (:147-149) uses the Xformd algebra
- * of the reference's `geometry` dependency and stays on the caller's side. */
+ * {t(3), q_yaw(4; w,x,y,z), cov_pos(9, column-major 3x3), cov_yaw}; the composition itself (:147-149) is host algebra on 7 + 36
+ * numbers per filter: viekf_seq_* keeps the node pose and covariance (viekf_seq_get_global_pose / _cov below). */
 int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge, viekf_mem where);
 
 /* Read-only evaluations at the current state -- what the reference's log writer records (src/vi_ekf/vi_ekf_log.cpp:6-67):
@@ -168,6 +168,10 @@ int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge
 int viekf_batch_eval_xdot(viekf_batch *b, const double *u, double *xdot, viekf_mem where);
 int viekf_batch_eval_h(viekf_batch *b, int32_t type, const int32_t *slot, double *zhat, viekf_mem where);
 int viekf_batch_get_cov_diag(viekf_batch *b, double *diag, viekf_mem where);
+/* a rectangular block of P of every filter, out [batch][ncols][nrows] (column-major per filter): what get_global_cov reads
+ * of P_ (P_.block<3,3>(xPOS|xATT, xPOS|xATT), src/vi_ekf/vi_ekf_kfr.cpp:28-31) without moving the whole covariance */
+int viekf_batch_get_cov_block(viekf_batch *b, int32_t row0, int32_t col0, int32_t nrows, int32_t ncols, double *out,
+                              viekf_mem where);
 
 /* Bounded device-side history for delayed measurements (the reference rewinds its 250-deep ring of (x,P,t),
  * include/vi_ekf.h:50,156-160, src/vi_ekf/vi_ekf_meas.cpp:45-63).  viekf_batch_history_resize allocates `depth`
@@ -235,10 +239,24 @@ int viekf_seq_keep_only_features(viekf_seq *s, const int32_t *ids, int32_t count
 int viekf_seq_tracked_features(viekf_seq *s, int32_t *ids /* [batch][num_features] */, int32_t *len /* [batch] */);
 int viekf_seq_status(viekf_seq *s, double *t_now, int32_t *ring_index, int32_t *queued, int32_t *inputs);
 
+/* Global pose and covariance (relative navigation: the filter state is relative to the last keyframe node).
+ *   viekf_seq_get_global_pose   VIEKF::get_global_pose, get_current_node_global_pose   src/vi_ekf/vi_ekf_kfr.cpp:14-21, vi_ekf.cpp:192-195
+ *   viekf_seq_get_global_cov    VIEKF::get_global_cov, propagate_global_covariance      src/vi_ekf/vi_ekf_kfr.cpp:23-53
+ * and the node update at the end of keyframe_reset (:147-150) happens inside viekf_seq_keep_only_features whenever it resets.
+ * SE(3) convention (the reference's Xformd lives in its absent `geometry` submodule; this is the one used here and restated in
+ * oracle/seq_oracle.py): a transform is {t(3), q(4; w,x,y,z)} with q the PASSIVE rotation of src/quat.cpp (rota(v) = R(q)^T v);
+ *   composition  T1 * T2 = { t1 + q1.rota(t2),  q1 (x) q2 };     Adj(T) = [ R  [t]x R ; 0  R ],  R = q.R()   (6x6, [pos; att])
+ *   get_global_pose = node * {x[POS], x[ATT]};     edge covariance = diag-blocks {P[POS,POS], 0 ..., P(ATT+2, ATT+2)} (:59-63,126)
+ *   node covariance += Adj(node)^T cov_edge Adj(node);  node = node * edge    (in that order, :149-150)
+ *   get_global_cov = node covariance + Adj(node)^T C Adj(node),  C = the [POS,ATT] x [POS,ATT] blocks of P.
+ * pose [batch][7] = {t, q}; node [batch][7] (may be NULL): the current node's global pose; cov [batch][36] column-major 6x6. */
+int viekf_seq_get_global_pose(viekf_seq *s, double *pose, double *node);
+int viekf_seq_get_global_cov(viekf_seq *s, double *cov);
+
 /* VIEKF::init_logger / disable_logger, src/vi_ekf/vi_ekf_log.cpp:69-117: opens <root><name>_{ACC,...,INV_DEPTH,state,cov,feat_id,
  * input,xdot,kf,global_pose}.log and _config.txt / _debug.txt and records filter `filter` of the batch from then on -- the binary
  * record layouts of log_state (:6-35) and log_measurement (:52-67), i.e. what matlab/plot_ekf.m reads.  The global_pose record
- * holds the pose relative to the current keyframe node (see viekf_batch_keyframe_reset). */
+ * is get_global_pose (node * relative pose), as :33-34 writes it. */
 int viekf_seq_init_logger(viekf_seq *s, const char *root_filename, const char *ekf_name, int32_t filter);
 int viekf_seq_disable_logger(viekf_seq *s);
 #ifdef __cplusplus

@@ -29,6 +29,27 @@ class _Meas:
     __slots__ = ("t", "type", "z", "R", "active", "id", "depth", "handled")
 
 
+# ---- SE(3) algebra of the global node frame (vi_ekf_kfr.cpp:14-53,147-150).  The reference's Xformd comes from its absent
+# `geometry` submodule; the convention is the one stated in include/viekf.h: T = {t, q}, q passive (src/quat.cpp),
+#   T1 * T2 = {t1 + q1.rota(t2), q1 (x) q2},   Adj(T) = [[R, [t]x R], [0, R]],  R = q.R().
+# Written with rotation matrices (oracle/np_twin.py), not a transliteration of the product's quaternion code.
+def xform_mul(T1, T2):
+    from oracle import np_twin as tw
+    T1, T2 = np.asarray(T1, float), np.asarray(T2, float)
+    return np.concatenate([T1[:3] + tw.Rmat(T1[3:]).T @ T2[:3], tw.qmul(T1[3:], T2[3:])])
+
+
+def xform_adj(T):
+    from oracle import np_twin as tw
+    T = np.asarray(T, float)
+    R = tw.Rmat(T[3:])
+    A = np.zeros((6, 6))
+    A[:3, :3] = R
+    A[:3, 3:] = tw.skew(T[:3]) @ R
+    A[3:, 3:] = R
+    return A
+
+
 class SeqOracle:
     def __init__(self, filt, keyframe_overlap_threshold=0.8, state_hist=LEN_STATE_HIST, meas_hist=LEN_MEAS_HIST):
         self.f = filt
@@ -46,6 +67,8 @@ class SeqOracle:
         self.keyframe_features = []
         self.log = []                       # what would go to cerr
         self.keyframe_edges = []
+        self.node = np.array([0.0, 0, 0, 1, 0, 0, 0])      # current_node_global_pose_ = Identity (vi_ekf.cpp:38)
+        self.node_cov = np.zeros((6, 6))                    # global_pose_cov_ (vi_ekf.cpp:39)
         self.rec = None                     # what the reference's log writer would record (enable_records)
         self._save()
 
@@ -58,7 +81,27 @@ class SeqOracle:
         ids = list(self.f.feature_ids)
         idv = np.array([float(ids[i]) if i < len(ids) else -1.0 for i in range(self.f.N)])
         self.rec["state"].append(dict(t=t, x=self.f.x.copy(), Pd=np.diag(self.f.P).copy(), u=np.asarray(ub).copy(),
-                                      xdot=np.asarray(xdot).copy(), ids=idv))
+                                      xdot=np.asarray(xdot).copy(), ids=idv, gpose=self.get_global_pose()))
+
+    # -- vi_ekf_kfr.cpp:14-53 -------------------------------------------------------------------------------------
+    def get_global_pose(self):
+        x = self.f.x
+        return xform_mul(self.node, np.concatenate([x[0:3], x[6:10]]))
+
+    def get_global_cov(self):
+        P = self.f.P
+        idx = [0, 1, 2, 6, 7, 8]                            # the POS and ATT blocks (vi_ekf_kfr.cpp:28-31)
+        A = xform_adj(self.node)
+        return self.node_cov + A.T @ P[np.ix_(idx, idx)] @ A
+
+    def _node_update(self, edge):
+        """end of keyframe_reset (vi_ekf_kfr.cpp:147-150): covariance first, with the node pose before it moves"""
+        C = np.zeros((6, 6))
+        C[:3, :3] = np.asarray(edge[7:16]).reshape(3, 3, order="F")
+        C[5, 5] = edge[16]
+        A = xform_adj(self.node)
+        self.node_cov = self.node_cov + A.T @ C @ A
+        self.node = xform_mul(self.node, edge[:7])
 
     # -- ring <-> live filter -------------------------------------------------------------------------------------
     def _save(self):
@@ -218,6 +261,7 @@ class SeqOracle:
         if self.f.use_keyframe_reset and len(self.keyframe_features) > 0 and \
                 overlap / float(len(self.keyframe_features)) < self.kf_thresh:
             self.keyframe_edges.append(self.f.keyframe_reset_edge())
+            self._node_update(self.keyframe_edges[-1])
             self.keyframe_features = list(features)
         elif self.f.use_keyframe_reset and len(self.keyframe_features) == 0:
             self.keyframe_features = list(features)

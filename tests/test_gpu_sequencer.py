@@ -129,8 +129,9 @@ def test_log_writer_matches_reference_records(tmp_path, delay):
         ref = np.stack([np.concatenate([[r["t"]], r[key]]) for r in rec["state"]])
         assert_close(a, ref, name)
     gp = load("global_pose.log", 8)
-    ref = np.stack([np.concatenate([[r["t"]], r["x"][0:3], r["x"][6:10]]) for r in rec["state"]])
+    ref = np.stack([np.concatenate([[r["t"]], r["gpose"]]) for r in rec["state"]])
     assert_close(gp, ref, "global_pose.log")     # (no keyframe reset in this run: node pose = identity)
+    assert (ref[:, 1:4] == np.stack([r["x"][0:3] for r in rec["state"]])).all()
     for mtype, name, width in ((orc.FEAT, "FEAT.log", 1 + 2 + 2 + 1 + 1), (orc.ALT, "ALT.log", 1 + 1 + 1 + 1)):
         a = load(name, width)
         ref = np.stack(rec["meas"][mtype])
@@ -142,3 +143,64 @@ def test_log_writer_matches_reference_records(tmp_path, delay):
     cfg = open(root + "ekf_config.txt").read().splitlines()
     assert cfg[0].startswith("Test Num: ") and cfg[-1].startswith("min_depth: ") and len(cfg) == 17
     assert cfg[-2] == "num features: %d" % N
+
+
+@pytest.mark.gpu
+def test_global_pose_and_covariance_through_keyframe_resets(tmp_path):
+    """VIEKF::get_global_pose / get_global_cov and the node update at the end of keyframe_reset (vi_ekf_kfr.cpp:14-53,147-150)
+    through three resets, against the restated plumbing; the global_pose log record is global after a reset"""
+    B, N, lf = 2, 6, 1
+    root = str(tmp_path) + "/"
+    g, sg, os_, _, _ = _run(B, N, seed=21, delay=0.0, steps=25, log_root=root, log_filter=lf)
+    t = 0.004 * 24
+    rng = np.random.default_rng(3)
+    R = np.eye(2) * 10.0
+
+    def fly(k):
+        nonlocal t
+        for _ in range(k):
+            t += 0.004
+            u = np.tile(np.array([0.3, -0.2, -9.80665, 0.02, 0.01, 0.2]), (B, 1)) + rng.normal(0, 0.3, (B, 6))
+            sg.propagate_state(u, t)
+            for b in range(B):
+                os_[b].propagate_state(u[b], t)
+
+    def keep(ids):
+        arr = np.array([list(ids) + [-1] * (6 - len(ids))] * B)
+        did, _ = sg.keep_only_features(arr)
+        for b in range(B):
+            os_[b].keep_only_features(list(ids))
+        return bool(did.all())
+
+    def check(what):
+        pose, node = sg.get_global_pose()
+        cov = sg.get_global_cov()
+        for b in range(B):
+            assert_close(node[b], os_[b].node, "node pose " + what)
+            assert_close(pose[b], os_[b].get_global_pose(), "global pose " + what)
+            assert_close(cov[b], os_[b].get_global_cov(), "global covariance " + what)
+        return node
+
+    assert not keep([0, 1, 2, 3, 4, 5])            # first call only records the keyframe features
+    check("before any reset")
+    fly(5)
+    assert keep([0, 2, 5])                         # 3 of 6 < 0.8: reset 1
+    fly(7)
+    check("after reset 1")
+    assert keep([0])                               # 1 of 3: reset 2
+    fly(4)
+    check("after reset 2")
+    for i in range(3):                             # three new features (the filter numbers them 6, 7, 8 itself)
+        z = rng.uniform(150, 450, (B, 2))
+        rg = sg.add_measurement(t, z, orc.FEAT, R, True, id=6 + i)
+        for b in range(B):
+            assert os_[b].add_measurement(t, z[b], orc.FEAT, R, True, 6 + i, float("nan")) == rg[b] == orc.MEAS_NEW_FEATURE
+    assert keep([6, 7, 8])                         # 0 of 1: reset 3, feature 0 dropped
+    fly(6)
+    node = check("after reset 3")
+    assert np.abs(node[:, :3]).max() > 1e-4 and np.abs(node[:, 3] - 1.0).max() > 1e-9   # the node really moved and turned
+    sg.disable_logger()
+    gp = np.fromfile(root + "ekf_global_pose.log", dtype=np.float64).reshape(-1, 8)
+    ref = np.stack([np.concatenate([[r["t"]], r["gpose"]]) for r in os_[lf].rec["state"]])
+    assert_close(gp, ref, "global_pose.log through resets")
+    assert np.abs(ref[-1, 1:4] - os_[lf].rec["state"][-1]["x"][0:3]).max() > 1e-6   # global != node-relative by now

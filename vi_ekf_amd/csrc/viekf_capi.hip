@@ -734,6 +734,27 @@ int viekf_batch_get_cov_diag(viekf_batch* b, double* diag, viekf_mem where) {
   return VIEKF_OK;
 }
 
+int viekf_batch_get_cov_block(viekf_batch* b, int32_t row0, int32_t col0, int32_t nrows, int32_t ncols, double* out,
+                              viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!out) return fail(VIEKF_ERR_INVALID, "out is null");
+  if (row0 < 0 || col0 < 0 || nrows < 1 || ncols < 1 || row0 + nrows > b->n || col0 + ncols > b->n)
+    return fail(VIEKF_ERR_INVALID, "block outside the covariance");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t ob = sizeof(double) * (size_t)b->B * nrows * ncols;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(ob))) return rc;
+  double* d_o = where == VIEKF_DEVICE ? out : static_cast<double*>(stage_take(b, ob));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_cov_block, dim3((nrows * ncols + 63) / 64, b->B), dim3(64), 0, b->stream, a, row0, col0, nrows, ncols, d_o);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
 static size_t hist_nx(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->nxs; }
 static size_t hist_nP(const viekf_batch* b) { return sizeof(double) * (size_t)b->B * b->n * b->ld; }
 static double* slot_x(const viekf_batch* b, int slot) { return reinterpret_cast<double*>(reinterpret_cast<char*>(b->h_x) + hist_nx(b) * slot); }

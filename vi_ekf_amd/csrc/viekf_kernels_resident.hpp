@@ -556,7 +556,7 @@ __device__ __forceinline__ void res_body_items(const ResShared& S, const double*
 }
 // how many of the 8 N body-column items of an update the service wave sweeps (after its chain), by worker-wave count
 template <int NWV>
-__device__ __forceinline__ int res_service_items(int N) { return (NWV <= 3) ? min(8 * N, 128) : 0; }
+__device__ __forceinline__ int res_service_items(int N) { return (NWV == 3) ? min(8 * N, 128) : 0; }
 
 template <int RB, int TW, bool MP>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {

@@ -1099,6 +1099,14 @@ __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
   if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
 }
 
+// a rectangular block P[r0 .. r0+nr, c0 .. c0+nc) of every filter -> out [B][nc][nr] (column-major per filter)
+__global__ void k_cov_block(StreamArgs a, int r0, int c0, int nr, int nc, double* __restrict__ out) {
+  const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B || e >= nr * nc) return;
+  const int c = e / nr, r = e - c * nr;
+  out[(long)b * nr * nc + e] = a.P[(long)b * a.n * a.ld + (r0 + r) + (long)(c0 + c) * a.ld];
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, int zdim, int rdim,
                                                       const double* __restrict__ z_all, const int* __restrict__ slot_all,

@@ -37,6 +37,55 @@ void rota(const double* q, const double* v, double* o) {   // src/quat.cpp:279-2
   for (int i = 0; i < 3; i++) o[i] = v[i] + q[0] * t[i] + c[i];
 }
 
+void otimes(const double* a, const double* b, double* o) {   // src/quat.cpp:304-312
+  const double r0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double r1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double r2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double r3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+}
+
+// T1 * T2 = { t1 + q1.rota(t2), q1 (x) q2 }  (the SE(3) convention stated in include/viekf.h; transforms are {t(3), q(4)})
+void xform_compose(const double* T1, const double* T2, double* out) {
+  double r[3], q[4];
+  rota(T1 + 3, T2, r);
+  otimes(T1 + 3, T2 + 3, q);
+  for (int i = 0; i < 3; i++) out[i] = T1[i] + r[i];
+  for (int i = 0; i < 4; i++) out[3 + i] = q[i];
+}
+
+// out (6x6, column-major) += Adj(T)^T C Adj(T),  Adj(T) = [ R  [t]x R ; 0  R ],  R = q.R() (passive, src/quat.cpp:226-242)
+// -- VIEKF::propagate_global_covariance, src/vi_ekf/vi_ekf_kfr.cpp:47-53
+void add_adj_cov(const double* T, const double* C, double* out) {
+  const double w = T[3], x = T[4], y = T[5], z = T[6];
+  const double R[3][3] = {{1 - 2 * y * y - 2 * z * z, 2 * x * y + 2 * w * z, 2 * x * z - 2 * w * y},
+                          {2 * x * y - 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z + 2 * w * x},
+                          {2 * x * z + 2 * w * y, 2 * y * z - 2 * w * x, 1 - 2 * x * x - 2 * y * y}};
+  const double S[3][3] = {{0, -T[2], T[1]}, {T[2], 0, -T[0]}, {-T[1], T[0], 0}};
+  double A[6][6] = {};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      A[i][j] = R[i][j];
+      A[3 + i][3 + j] = R[i][j];
+      double sr = 0.0;
+      for (int k = 0; k < 3; k++) sr += S[i][k] * R[k][j];
+      A[i][3 + j] = sr;
+    }
+  double CA[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double v = 0.0;
+      for (int k = 0; k < 6; k++) v += C[i + 6 * k] * A[k][j];
+      CA[i][j] = v;
+    }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double v = 0.0;
+      for (int k = 0; k < 6; k++) v += A[k][i] * CA[k][j];
+      out[i + 6 * j] += v;
+    }
+}
+
 }  // namespace
 
 struct viekf_seq {
@@ -51,6 +100,8 @@ struct viekf_seq {
   std::vector<std::vector<int32_t>> ids;                           // current_feature_ids_ per filter
   std::vector<int32_t> next_id;                                    // next_feature_id_ per filter
   std::vector<std::vector<int32_t>> kf_feats;                      // keyframe_features_ per filter
+  std::vector<double> node;                                        // current_node_global_pose_ per filter: {t(3), q(4)}
+  std::vector<double> node_cov;                                    // global_pose_cov_ per filter: 6x6 column-major
   std::string err;
   // binary logs of ONE filter of the batch, file for file what VIEKF::init_logger opens (src/vi_ekf/vi_ekf_log.cpp:79-117)
   std::vector<std::ofstream> log;                                  // empty = logging off
@@ -90,11 +141,12 @@ void log_state(viekf_seq* s, double t, const std::vector<double>& x, const std::
     const double idd = i < (int)s->ids[f].size() ? (double)s->ids[f][i] : -1.0;
     wr(s->log[LOG_FEATURE_IDS], &idd, 1);
   }
-  // The reference writes current_node_global_pose_ * (p, q) here; that composition lives in its `geometry` dependency (not
-  // part of this library, see viekf_batch_keyframe_reset): this record holds the pose relative to the current keyframe
-  // node, which is the global pose until the first keyframe reset.
+  // get_global_pose() = current_node_global_pose_ * (p, q)   (vi_ekf_log.cpp:33-34, vi_ekf_kfr.cpp:14-21)
   const double* xf = x.data() + (size_t)f * nx;
-  wr(s->log[LOG_GLOBAL_POSE], &t, 1); wr(s->log[LOG_GLOBAL_POSE], xf + 0, 3); wr(s->log[LOG_GLOBAL_POSE], xf + 6, 4);
+  const double rel[7] = {xf[0], xf[1], xf[2], xf[6], xf[7], xf[8], xf[9]};
+  double gp[7];
+  xform_compose(s->node.data() + 7 * (size_t)f, rel, gp);
+  wr(s->log[LOG_GLOBAL_POSE], &t, 1); wr(s->log[LOG_GLOBAL_POSE], gp, 3); wr(s->log[LOG_GLOBAL_POSE], gp + 3, 4);
 }
 
 int fetch_state_and_diag(viekf_seq* s, std::vector<double>& x, std::vector<double>& Pd) {
@@ -235,6 +287,9 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   s->ids.assign(B, {});
   s->next_id.assign(B, 0);
   s->kf_feats.assign(B, {});
+  s->node.assign((size_t)B * 7, 0.0);                              // Xformd::Identity(), vi_ekf.cpp:38
+  for (int b = 0; b < B; b++) s->node[7 * (size_t)b + 3] = 1.0;
+  s->node_cov.assign((size_t)B * 36, 0.0);                         // vi_ekf.cpp:39
   *out = s;
   return VIEKF_OK;
 }
@@ -423,9 +478,54 @@ int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count
     }
   if (edges) std::memset(edges, 0, sizeof(double) * 17 * (size_t)B);
   if (any_reset) {
-    if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), edges, VIEKF_HOST)) return rc;
+    std::vector<double> eb((size_t)B * 17, 0.0);
+    if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), eb.data(), VIEKF_HOST)) return rc;
+    for (int b = 0; b < B; b++) {
+      if (!reset[b]) continue;
+      const double* e = eb.data() + 17 * (size_t)b;                // {t(3), q_yaw(4), cov_pos(9), cov_yaw}
+      double C[36] = {};                                           // edge.cov: position block and the yaw variance (:59-63,126)
+      for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 3; r++) C[r + 6 * c] = e[7 + r + 3 * c];
+      C[5 + 6 * 5] = e[16];
+      double* nd = s->node.data() + 7 * (size_t)b;
+      add_adj_cov(nd, C, s->node_cov.data() + 36 * (size_t)b);      // :149 (with the node pose BEFORE it moves)
+      double nn[7];
+      xform_compose(nd, e, nn);                                    // :150
+      std::memcpy(nd, nn, sizeof nn);
     }
+    if (edges) std::memcpy(edges, eb.data(), sizeof(double) * 17 * (size_t)B);
+  }
   if (did_reset) std::memcpy(did_reset, reset.data(), B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_get_global_pose(viekf_seq* s, double* pose, double* node) {   // vi_ekf_kfr.cpp:14-21, vi_ekf.cpp:192-195
+  if (!s || !pose) return VIEKF_ERR_INVALID;
+  const int nx = 17 + 5 * s->N;
+  std::vector<double> x((size_t)s->B * nx);
+  if (int rc = viekf_batch_get_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  for (int b = 0; b < s->B; b++) {
+    const double* xf = x.data() + (size_t)b * nx;
+    const double rel[7] = {xf[0], xf[1], xf[2], xf[6], xf[7], xf[8], xf[9]};
+    xform_compose(s->node.data() + 7 * (size_t)b, rel, pose + 7 * (size_t)b);
+  }
+  if (node) std::memcpy(node, s->node.data(), sizeof(double) * 7 * (size_t)s->B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_get_global_cov(viekf_seq* s, double* cov) {   // vi_ekf_kfr.cpp:23-35
+  if (!s || !cov) return VIEKF_ERR_INVALID;
+  std::vector<double> blk((size_t)s->B * 81);                       // P[0:9, 0:9]: holds the POS (0..2) and ATT (6..8) blocks
+  if (int rc = viekf_batch_get_cov_block(s->core, 0, 0, 9, 9, blk.data(), VIEKF_HOST)) return rc;
+  for (int b = 0; b < s->B; b++) {
+    const double* Pb = blk.data() + 81 * (size_t)b;
+    double C[36];
+    for (int c = 0; c < 6; c++)
+      for (int r = 0; r < 6; r++) C[r + 6 * c] = Pb[(r < 3 ? r : r + 3) + 9 * (c < 3 ? c : c + 3)];
+    double* o = cov + 36 * (size_t)b;
+    std::memcpy(o, s->node_cov.data() + 36 * (size_t)b, sizeof(double) * 36);
+    add_adj_cov(s->node.data() + 7 * (size_t)b, C, o);
+  }
   return VIEKF_OK;
 }
 

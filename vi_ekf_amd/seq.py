@@ -23,6 +23,8 @@ def _bind():
     L.viekf_seq_status.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.viekf_seq_init_logger.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32]
     L.viekf_seq_disable_logger.argtypes = [vp]
+    L.viekf_seq_get_global_pose.argtypes = [vp, vp, vp]
+    L.viekf_seq_get_global_cov.argtypes = [vp, vp]
     L._seq_bound = True
     return L
 
@@ -89,6 +91,20 @@ class SeqVIEKF:
 
     def disable_logger(self):
         capi.check(self._L.viekf_seq_disable_logger(self._h))
+
+    def get_global_pose(self):
+        """-> (pose [B][7], node [B][7]) = VIEKF::get_global_pose / get_current_node_global_pose, {t(3), q(4)}
+        (reference vi_ekf_kfr.cpp:14-21; SE(3) convention in include/viekf.h)"""
+        pose = np.zeros((self.B, 7))
+        node = np.zeros((self.B, 7))
+        capi.check(self._L.viekf_seq_get_global_pose(self._h, _p(pose), _p(node)))
+        return pose, node
+
+    def get_global_cov(self):
+        """-> [B][6][6] = VIEKF::get_global_cov (reference vi_ekf_kfr.cpp:23-53), indexed [b, row, col]"""
+        cov = np.zeros((self.B, 6, 6))
+        capi.check(self._L.viekf_seq_get_global_cov(self._h, _p(cov)))
+        return np.ascontiguousarray(cov.transpose(0, 2, 1))
 
     def tracked_features(self):
         ids = np.zeros((self.B, self.N), dtype=np.int32)
