@@ -214,6 +214,7 @@ int viekf_batch_step_n(viekf_batch *b, int32_t K, const double *u, const double 
  *   viekf_seq_handle_measurements  VIEKF::handle_measurements                        src/vi_ekf/vi_ekf_meas.cpp:6-127
  *   viekf_seq_keep_only_features   VIEKF::keep_only_features (+ keyframe trigger)    src/vi_ekf/vi_ekf_feat.cpp:81-142
  *   viekf_seq_tracked_features     VIEKF::tracked_features                           src/vi_ekf/vi_ekf_feat.cpp:75-78
+ *   viekf_seq_init_feature         VIEKF::init_feature                               src/vi_ekf/vi_ekf_feat.cpp:6-47
  * The state history (x, P, t) ring (include/vi_ekf.h:50,156-160; 250 deep there) is the batch's device snapshot ring with
  * `state_hist` slots; a rewind restores x and P but not the feature count, like the reference's ring.  Quirks kept: the
  * input queue stores the input already rotated by q_b_u and the replay rotates it again (vi_ekf.cpp:265-271); a feature
@@ -237,6 +238,8 @@ int viekf_seq_handle_measurements(viekf_seq *s, int32_t *gated_ids, int32_t cap,
  * triggered by the overlap test and their edges (viekf_batch_keyframe_reset) */
 int viekf_seq_keep_only_features(viekf_seq *s, const int32_t *ids, int32_t count, uint8_t *did_reset, double *edges);
 int viekf_seq_tracked_features(viekf_seq *s, int32_t *ids /* [batch][num_features] */, int32_t *len /* [batch] */);
+/* pix [batch][2]; depth [batch] (NULL = NaN -> 2 min_depth); mask [batch] (NULL = all); ok [batch] (may be NULL): 1 if a slot was taken */
+int viekf_seq_init_feature(viekf_seq *s, const double *pix, const double *depth, const uint8_t *mask, int32_t *ok);
 int viekf_seq_status(viekf_seq *s, double *t_now, int32_t *ring_index, int32_t *queued, int32_t *inputs);
 
 /* Global pose and covariance (relative navigation: the filter state is relative to the last keyframe node).

@@ -351,6 +351,25 @@ int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double
   return VIEKF_OK;
 }
 
+// VIEKF::init_feature(l, id, depth), src/vi_ekf/vi_ekf_feat.cpp:6-47, with the sequencer's feature bookkeeping: the caller's id
+// is ignored like there (:29-30: the filter pushes its own counter)
+int viekf_seq_init_feature(viekf_seq* s, const double* pix, const double* depth, const uint8_t* mask, int32_t* ok) {
+  if (!s || !pix) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<uint8_t> m(B, 1);
+  if (mask) m.assign(mask, mask + B);
+  for (int b = 0; b < B; b++)
+    if ((int)s->ids[b].size() >= s->N) m[b] = 0;                   // :9-10 (full: refused)
+  std::vector<double> dep(B, NAN);
+  if (depth) dep.assign(depth, depth + B);
+  std::vector<int32_t> okv(B, 0);
+  if (int rc = viekf_batch_init_feature(s->core, pix, dep.data(), m.data(), okv.data(), VIEKF_HOST)) return rc;
+  for (int b = 0; b < B; b++)
+    if (m[b] && okv[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+  if (ok) std::memcpy(ok, okv.data(), sizeof(int32_t) * B);
+  return VIEKF_OK;
+}
+
 int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap, int32_t* gated_count) {
   if (!s) return VIEKF_ERR_INVALID;
   const int B = s->B;
