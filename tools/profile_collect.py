@@ -18,7 +18,7 @@ def find(sub, pat):
     fs = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
     if not fs:
         raise SystemExit("missing %s/%s" % (sub, pat))
-    return fs[0]
+    return max(fs, key=os.path.getmtime)   # (gpurun merges into gpurun_out: older runs' files stay around)
 
 
 shutil.copy(find("stats", "*kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
@@ -39,7 +39,7 @@ def counter(sub, name, out):
 fe = counter("fetch", "FETCH_SIZE", tag + "_pmc_fetch.csv")
 wr = counter("write", "WRITE_SIZE", tag + "_pmc_write.csv")
 fb, wb = fe["mean_kb"] * 1024.0, wr["mean_kb"] * 1024.0
-j = {"config": {"batch": 1024, "n_feat": 50, "kernel": "k_step_resident<3,7>"},
+j = {"config": {"batch": 1024, "n_feat": 50, "kernel": "k_step_resident<7,3> (two 256-thread workgroups per CU)"},
      "command": "tools/profile_run.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py "
                 "--steps 10 --warmup 2 --no-cpu-baseline (separate passes)",
      "raw": {"fetch": fe, "write": wr}, "fetch_bytes_raw": fb, "fetch_bytes_x2_gfx950": 2 * fb, "write_bytes": wb,

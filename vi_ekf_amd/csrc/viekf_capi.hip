@@ -54,6 +54,7 @@ struct viekf_batch {
   size_t res_lds = 0;
   DevParams dp;
   DevParams* d_dp = nullptr;
+  bool upper_stale = false;   // the grouped update left P's upper triangle stale (valid: the lower triangle); see ensure_full_P
   int hist_depth = 0;
   int live_slot = -1;        // >= 0: the live (x, P) ARE this slot of the history ring (d_x / d_P point into it)
   double *home_x = nullptr, *home_P = nullptr;   // the batch's own buffers (live state while live_slot < 0)
@@ -120,17 +121,32 @@ size_t lds_propagate(const viekf_batch* b) {
 }
 size_t lds_update(const viekf_batch* b) { return sizeof(double) * (size_t)(b->nxs + 5 * b->n + 32); }
 
+// A grouped update (k_update_feat_blocked) keeps only the lower triangle of P current; the matrix-core propagate reads only
+// that and rewrites all of P.  Everything else reads P whole: mirror the lower triangle up first.
+int ensure_full_P(viekf_batch* b) {
+  if (!b->upper_stale) return VIEKF_OK;
+  StreamArgs a = make_args(b);
+  const int nt = (b->n + 31) / 32;
+  hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(nt * (nt + 1) / 2), b->B), dim3(256), 0, b->stream, a);
+  HIP_TRY(hipGetLastError());
+  b->upper_stale = false;
+  return VIEKF_OK;
+}
+
 bool stream_mfma_ok() {   // VIEKF_STREAM_BLOCKED=0 keeps the kernels without matrix-core passes (experiments)
   static const bool ok = []() { const char* e = getenv("VIEKF_STREAM_BLOCKED"); return !(e && atoi(e) == 0); }();
   return ok;
 }
 
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
+  if (!stream_mfma_ok())
+    if (int rc = ensure_full_P(b)) return rc;
   StreamArgs a = make_args(b);
-  if (stream_mfma_ok())   // feature/feature part on the fp64 matrix cores
+  if (stream_mfma_ok()) {   // feature/feature part on the fp64 matrix cores: reads the lower triangle, writes all of P
     hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2 + 8 * 16 * 17),
                        b->stream, a, d_u, d_dt);
-  else
+    b->upper_stale = false;
+  } else
     hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
                        d_dt);
   HIP_TRY(hipGetLastError());
@@ -139,6 +155,7 @@ int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
 
 int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, const double* d_R, int r_mode,
                   int* d_res) {
+  if (int rc = ensure_full_P(b)) return rc;   // (the panel loads read whole columns)
   StreamArgs a = make_args(b);
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
@@ -160,6 +177,7 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
     }
     hipLaunchKernelGGL(k_update_feat_blocked<512>, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb,
                        rsm, d_res);
+    b->upper_stale = true;
   } else {
     hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
                        d_slot, M, d_R, rsb, rsm, d_res);
@@ -230,6 +248,7 @@ bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family !
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
                     double* P_out = nullptr, int KP = 1) {
+  if (int rc = ensure_full_P(b)) return rc;
   StreamArgs a = make_args(b);
   if (x_out) { a.x_out = x_out; a.P_out = P_out; }   // (only meaningful for a single-chunk launch)
   long rsb = 0, rsm = 0;
@@ -427,6 +446,7 @@ int viekf_batch_reset(viekf_batch* b) {
   StreamArgs a = make_args(b);
   hipLaunchKernelGGL(k_reset, dim3(b->B), dim3(256), 0, b->stream, a, b->d_x0, b->d_Pdiag);
   HIP_TRY(hipGetLastError());
+  b->upper_stale = false;
   HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
@@ -480,9 +500,11 @@ int viekf_batch_get_state(viekf_batch* b, double* x, double* P, int32_t* len_fea
   if (x)
     HIP_TRY(hipMemcpy2DAsync(x, sizeof(double) * b->nx, b->d_x, sizeof(double) * b->nxs, sizeof(double) * b->nx, b->B,
                              kind, b->stream));
-  if (P)
+  if (P) {
+    if (int rc = ensure_full_P(b)) return rc;
     HIP_TRY(hipMemcpy2DAsync(P, sizeof(double) * b->n, b->d_P, sizeof(double) * b->ld, sizeof(double) * b->n,
                              (size_t)b->B * b->n, kind, b->stream));
+  }
   if (len_features) HIP_TRY(hipMemcpyAsync(len_features, b->d_len, sizeof(int32_t) * b->B, kind, b->stream));
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
@@ -508,6 +530,7 @@ int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, cons
     const long tot = (long)b->n * b->n;
     hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((tot + 255) / 256), b->B), dim3(256), 0, b->stream, a);
     HIP_TRY(hipGetLastError());
+    b->upper_stale = false;
   }
   if (len_features) HIP_TRY(hipMemcpyAsync(b->d_len, len_features, sizeof(int32_t) * b->B, kind, b->stream));
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
@@ -628,6 +651,7 @@ int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
 
 int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem where) {
   if (int rc = check_batch(b)) return rc;
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   if (!keep) return fail(VIEKF_ERR_INVALID, "keep must not be null");
   HIP_TRY(hipSetDevice(b->device));
   const size_t BN = (size_t)b->B * b->N;
@@ -650,6 +674,7 @@ int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_
 
 int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge, viekf_mem where) {
   if (int rc = check_batch(b)) return rc;
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   HIP_TRY(hipSetDevice(b->device));
   const uint8_t* d_mask = nullptr;
   double* d_edge = nullptr;
@@ -738,6 +763,7 @@ int viekf_batch_get_cov_block(viekf_batch* b, int32_t row0, int32_t col0, int32_
                               viekf_mem where) {
   if (int rc = check_batch(b)) return rc;
   if (!out) return fail(VIEKF_ERR_INVALID, "out is null");
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   if (row0 < 0 || col0 < 0 || nrows < 1 || ncols < 1 || row0 + nrows > b->n || col0 + ncols > b->n)
     return fail(VIEKF_ERR_INVALID, "block outside the covariance");
   HIP_TRY(hipSetDevice(b->device));
@@ -784,6 +810,7 @@ int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
 
 static int history_copy(viekf_batch* b, int32_t slot, bool save) {
   if (int rc = check_batch(b)) return rc;
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
   HIP_TRY(hipSetDevice(b->device));
   const size_t nl = sizeof(int) * (size_t)b->B;
@@ -809,6 +836,7 @@ int viekf_batch_restore(viekf_batch* b, int32_t slot) { return history_copy(b, s
 
 int viekf_batch_select(viekf_batch* b, int32_t slot) {
   if (int rc = check_batch(b)) return rc;
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   if (slot < -1 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
   if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
   b->live_slot = slot;
@@ -823,6 +851,7 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   if (dst_slot < 0 || dst_slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
   if (dst_slot == b->live_slot) return viekf_batch_propagate(b, u, dt, where);
   HIP_TRY(hipSetDevice(b->device));
+  if (int rc = ensure_full_P(b)) return rc;
   const double *d_u = nullptr, *d_dt = nullptr;
   if (where == VIEKF_HOST)
     if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B))) return rc;
@@ -845,6 +874,7 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
 int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zdim, const double* R, int32_t rdim,
                        int32_t r_mode, const int32_t* slot, const uint8_t* active, int32_t* result, viekf_mem where) {
   if (int rc = check_batch(b)) return rc;
+  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
   if (!z || !R) return fail(VIEKF_ERR_INVALID, "z and R must not be null");
   if (type < 0 || type >= VIEKF_TOTAL_MEAS || type == VIEKF_PIXEL_VEL)
     return fail(VIEKF_ERR_UNSUPPORTED, "measurement type not supported (PIXEL_VEL is an empty TODO in the reference)");

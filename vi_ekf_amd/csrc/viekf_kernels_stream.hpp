@@ -200,12 +200,15 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     xs[xZ + 5 * i + 4] = rho + xd3[2] * dt;
   }
   // ---- save the body rows / columns of P before anything is overwritten
+  // (the matrix-core variant reads nothing above the diagonal outside the diagonal 48 x 48 super-tiles: after a grouped update
+  //  the rest of the upper triangle may be stale, see k_update_feat_blocked; P is symmetric, so the body rows are the body columns)
   for (int e = tid; e < 16 * nact; e += T) {
     const int k = e / nact, j = e % nact;
-    pbr[k * n + j] = P[k + (long)j * ld];
-    pbc[k * n + j] = P[j + (long)k * ld];
+    const double pc = P[j + (long)k * ld];
+    pbr[k * n + j] = MF ? pc : P[k + (long)j * ld];
+    pbc[k * n + j] = pc;
   }
-  for (int e = tid; e < 256; e += T) Pbb[e] = P[(e >> 4) + (long)(e & 15) * ld];
+  for (int e = tid; e < 256; e += T) Pbb[e] = MF ? P[max(e >> 4, e & 15) + (long)min(e >> 4, e & 15) * ld] : P[(e >> 4) + (long)(e & 15) * ld];
   __syncthreads();
   if (tid == 0) {  // body state step (after every feature thread has read the old body state through ctx)
     double dxb[16], xo[17];
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   double* diag = smem + L.diag; // running P(rho_f, rho_f)
   int* gsl = reinterpret_cast<int*>(smem + L.gsl);
   int* gml = gsl + BG;
+  __shared__ unsigned needw;    // 16-column blocks that hold a zeta column of a measurement still to come in this launch
   double* wz = smem + L.win;
   double* wR = wz + 2 * BWIN;
   int* wsl = reinterpret_cast<int*>(wR + 4 * BWIN);
@@ -682,7 +686,23 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       mbase = m0;
     }
     if (Gn == 0) continue;
+    // Which mirror tiles does the pass of this group have to write?  P is symmetric and only its lower triangle is read by the
+    // pass; the part above the diagonal is read (a) by the panel loads of LATER groups -- whole zeta columns -- and (b) by the
+    // matrix-core propagate inside its diagonal 48 x 48 super-tiles.  Everything else above the diagonal is left STALE (the
+    // host marks the batch and mirrors the lower triangle up before anything else reads P): mirrored full-P stores in every
+    // pass were half of this kernel's HBM writes.
+    if (tid == 0) needw = 0u;
     __syncthreads();
+    {
+      unsigned mine = 0u;
+      for (int e = m + tid; e < M; e += T) {
+        const int sl = slot_all[(long)b * M + e];
+        if (sl >= 0 && sl < len) { const int c = 16 + 3 * sl; mine |= (1u << (c >> 4)) | (1u << ((c + 1) >> 4)); }
+      }
+      if (mine) atomicOr(&needw, mine);
+    }
+    __syncthreads();
+    const unsigned need = needw;
     // ---- 1. panel <- the zeta columns of the group's features (coalesced along the rows); unused columns <- 0
     for (int i = tid; i < nact; i += T) {
 #pragma unroll 1
@@ -926,7 +946,8 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
             const int j = 16 * tj + lk + 4 * rg;
             if (ti < nt && i < nact && j < nact) {
               P[i + (long)j * ld] = pv[q][rg];
-              if (ti != tj) P[j + (long)i * ld] = pv[q][rg];   // the mirror tile
+              // the mirror tile (column block ti): only where somebody reads it before the next full symmetrisation
+              if (ti != tj && (((need >> ti) & 1u) || (tj >= 1 && (ti - 1) / 3 == (tj - 1) / 3))) P[j + (long)i * ld] = pv[q][rg];
             }
           }
         }
@@ -1092,6 +1113,30 @@ __global__ void k_symmetrize(StreamArgs a) {
   const double v = 0.5 * (P[i + (long)j * a.ld] + P[j + (long)i * a.ld]);
   P[i + (long)j * a.ld] = v;
   P[j + (long)i * a.ld] = v;
+}
+
+// upper triangle <- lower triangle (bit for bit), 32 x 32 tiles through LDS so that both sides are coalesced along the rows.
+// Runs when a grouped update left the upper triangle stale (k_update_feat_blocked) and something is about to read all of P.
+__global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
+  __shared__ double t[32][33];
+  const int b = blockIdx.y, n = a.n, nt = (n + 31) >> 5;
+  // tile pairs (ti >= tj) numbered row by row: blockIdx.x = ti (ti + 1) / 2 + tj
+  int ti = (int)((sqrtf(1.0f + 8.0f * (float)blockIdx.x) - 1.0f) * 0.5f);
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  if (ti >= nt) return;
+  double* P = a.P + (long)b * n * a.ld;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  for (int c = ly; c < 32; c += 8) {
+    const int i = 32 * ti + lx, j = 32 * tj + c;
+    t[c][lx] = (i < n && j < n) ? P[i + (long)j * a.ld] : 0.0;
+  }
+  __syncthreads();
+  for (int c = ly; c < 32; c += 8) {
+    const int i = 32 * tj + lx, j = 32 * ti + c;     // destination element (i, j) = source element (j, i)
+    if (i < n && j < n && i < j) P[i + (long)j * a.ld] = t[lx][c];   // (a diagonal tile: its strictly upper part only)
+  }
 }
 
 __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
