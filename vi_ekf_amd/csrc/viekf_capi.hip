@@ -163,20 +163,36 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass);
   // VIEKF_STREAM_BLOCKED=0 keeps the one-pass-per-measurement kernel (experiments)
   const bool blocked_ok = stream_mfma_ok();
-  const BlkLds BL(b->N, b->n, b->nxs);
-  const size_t blds = sizeof(double) * (size_t)BL.total;
-  if (blocked_ok && M >= 2 && b->n <= 512 && blds + 1024 <= 160 * 1024) {   // (+ the kernel's small static LDS)
-    // (a function attribute belongs to the DEVICE's copy of the kernel: one high-water mark per device, so that a process
-    //  driving several GPUs through hipSetDevice raises the limit on each of them)
-    static size_t attr_bytes[64] = {};
-    size_t& have = attr_bytes[b->device & 63];
+  // group size: the largest of 32 / 24 / 16 whose panel fits the LDS (fewer passes over P for the narrower filters)
+  int bg = 0;
+  size_t blds = 0;
+  // (measured: at N = 64 groups of 32 are SLOWER than 16 -- 1.96 vs 1.83 ms per step, the sequential panel phase grows with
+  //  the group -- while N = 100 gains 4 % from 24: the wider groups only where the passes dominate)
+  for (int cand : {32, 24, 16}) {
+    if (cand > 16 && b->n <= 256) continue;
+    const BlkLds BL(b->N, b->n, b->nxs, cand);
+    blds = sizeof(double) * (size_t)BL.total;
+    if (blds + 1024 <= 160 * 1024) { bg = cand; break; }   // (+ the kernel's small static LDS)
+  }
+  if (const char* e = getenv("VIEKF_BLOCK_GROUP")) {   // (experiments)
+    const int want = atoi(e);
+    if (want == 16 || want == 24 || want == 32) {
+      const BlkLds BL(b->N, b->n, b->nxs, want);
+      if (sizeof(double) * (size_t)BL.total + 1024 <= 160 * 1024) { bg = want; blds = sizeof(double) * (size_t)BL.total; }
+    }
+  }
+  if (blocked_ok && M >= 2 && b->n <= 512 && bg > 0) {
+    typedef void (*blk_kernel_t)(StreamArgs, const double*, const int*, int, const double*, long, long, int*);
+    const blk_kernel_t kern = bg == 32 ? k_update_feat_blocked<512, 32> : (bg == 24 ? k_update_feat_blocked<512, 24> : k_update_feat_blocked<512, 16>);
+    // (a function attribute belongs to the DEVICE's copy of the kernel: one high-water mark per device and instance, so that a
+    //  process driving several GPUs through hipSetDevice raises the limit on each of them)
+    static size_t attr_bytes[64][3] = {};
+    size_t& have = attr_bytes[b->device & 63][bg == 32 ? 2 : (bg == 24 ? 1 : 0)];
     if (blds > have) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_feat_blocked<512>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
       have = blds;
     }
-    hipLaunchKernelGGL(k_update_feat_blocked<512>, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb,
-                       rsm, d_res);
+    hipLaunchKernelGGL(kern, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb, rsm, d_res);
     b->upper_stale = true;
   } else {
     hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,

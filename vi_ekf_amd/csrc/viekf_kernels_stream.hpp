@@ -590,14 +590,14 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
 // keeping W alone (K costs two multiply-adds per operand instead of 127 KB of LDS) is what lets BG = 16 fit at N = 160.
 // LDS rows of W are 34 doubles apart: the MFMA operand reads (16 consecutive rows per k) then spread over the banks.
 // ------------------------------------------------------------------------------------------------
-constexpr int BG = 16;    // measurements per group
-constexpr int BLD = 34;   // LDS row stride (doubles) of the n x 32 panel
-constexpr int BWIN = 32;  // measurement-list entries staged per group
+// BG = measurements per group (template parameter: 16, 24 or 32 -- the largest whose panel fits the LDS, so that the narrower
+// filters of this family cross HBM fewer times); BLD = 2 BG + 2 = LDS row stride (doubles) of the n x 2 BG panel; BWIN = 2 BG
+// measurement-list entries staged per group
 
 struct BlkLds {
   int xs, lam, Wp, Si, sm, diag, gsl, win, total;   // offsets in doubles
-  __host__ __device__ BlkLds(int N, int n, int nxs) {
-    const int nr = (n + 15) & ~15;
+  __host__ __device__ BlkLds(int N, int n, int nxs, int BG) {
+    const int nr = (n + 15) & ~15, BLD = 2 * BG + 2, BWIN = 2 * BG;
     int o = 0;
     auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
     xs = take(nxs); lam = take(n); Wp = take(nr * BLD); Si = take(4 * BG); sm = take(32);   // sm: pzz[2][4] (+ spare)
@@ -608,7 +608,7 @@ struct BlkLds {
   }
 };
 
-template <int T>
+template <int T, int BG>
 __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const double* __restrict__ z_all,
                                                            const int* __restrict__ slot_all, int M,
                                                            const double* __restrict__ R_all, long r_stride_b,
@@ -617,7 +617,8 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n, ld = a.ld;
-  const BlkLds L(a.N, n, a.nxs);
+  constexpr int BLD = 2 * BG + 2, BWIN = 2 * BG;
+  const BlkLds L(a.N, n, a.nxs, BG);
   double* xs = smem + L.xs;
   double* lam = smem + L.lam;
   double* Wp = smem + L.Wp;     // panel of raw columns, turned into W pair by pair
