@@ -85,6 +85,11 @@ def test_wide_p_full_batch():
     run_full(1024, 150, 1, [0, 1023])
 
 
+def test_two_service_waves_full_batch():
+    """B=1024, N=64: the <6,6> instance with the body lanes on a second service wave (N + 14 > 64)"""
+    run_full(1024, 64, 2, [0, 255, 256, 1023])
+
+
 def test_two_filters_per_workgroup_sizes_between():
     """B=1024 at feature counts either side of the instance boundaries"""
     run_full(1024, 26, 2, [0, 300, 1023])

@@ -204,12 +204,13 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 
 // Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the N (N + 1) / 2 owned
 // 3x3 blocks are dealt round-robin to the NW * 64 worker threads, at most RB per thread.
-struct ResInst { int RB, NW, nmin, nmax, max_lds_kb; };
+struct ResInst { int RB, NW, nmin, nmax, max_lds_kb, NS; };   // NS: service waves (2: the body lanes on a wave of their own)
 const ResInst kResInst[] = {
-    {3, 2, 1, 25, 80},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
+    {3, 2, 1, 25, 80, 1},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
                      // runs under the other's sweeps
-    {7, 3, 26, 50, 80},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
-    {3, 7, 1, 50, 160},
+    {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
+    {3, 7, 1, 50, 160, 1},
+    {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
 
@@ -220,6 +221,7 @@ res_kernel_t res_kernel(int inst, bool multi = false) {   // multi: several prop
     case 0: return multi ? k_step_resident<3, 2, true> : k_step_resident<3, 2, false>;
     case 1: return multi ? k_step_resident<7, 3, true> : k_step_resident<7, 3, false>;
     case 2: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
+    case 3: return multi ? k_step_resident<6, 6, true, 2> : k_step_resident<6, 6, false, 2>;
   }
   return nullptr;
 }
@@ -274,7 +276,7 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   int m0 = 0;
   do {
     const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
-    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1), dim3(b->B), dim3((r.NW + 1) * 64), b->res_lds, b->stream, a, b->res_TR,
+    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1), dim3(b->B), dim3((r.NW + r.NS) * 64), b->res_lds, b->stream, a, b->res_TR,
                        b->res_TC, ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
@@ -504,7 +506,7 @@ int viekf_batch_set_kernel(viekf_batch* b, int32_t family) {
   if (int rc = check_batch(b)) return rc;
   if (family < 0 || family > 2) return fail(VIEKF_ERR_INVALID, "kernel family must be 0, 1 or 2");
   if (family == 2 && b->res_inst < 0)
-    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (1..50)");
+    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (1..64)");
   b->family = family;
   return VIEKF_OK;
 }

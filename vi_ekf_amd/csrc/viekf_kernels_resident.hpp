@@ -560,7 +560,7 @@ template <int NWV>
 //  0.424 / 0.415 / 0.431 / 0.457 ms per step)
 __device__ __forceinline__ int res_service_items(int N) { return (NWV == 3) ? ((5 * N + 7) & ~7) : 0; }
 
-template <int RB, int TW, bool MP>
+template <int RB, int TW, bool MP, int T = TW + 64>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
   double* P = a.P + (long)S.b * n * ld;
@@ -845,7 +845,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     __builtin_amdgcn_s_setprio(1);
     const double fixpending = S.sm[40 + (par ^ 1)];   // posted before the barrier by the service wave
     const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
-    const double nanw = S.sm[44 + cnt % 3];
+    const double nanw = S.sm[44 + cnt % 3] + S.sm[52 + cnt % 3];   // (the second word: a second service wave's rows)
     sq = S.mseq[min(mnext, MCAP - 1)];                 // next iteration's table entry (static data)
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
@@ -970,7 +970,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       RES_STAMP(S, tid == 0 && ch < 3, 225 + 4 * ch);
       __syncthreads();   // S1: the chunk image is complete
       RES_STAMP(S, tid == 0 && ch < 3, 226 + 4 * ch);
-      res_store_chunk<TW + 64>(a, S, f0, f1, gtid);
+      res_store_chunk<T>(a, S, f0, f1, gtid);
       RES_STAMP(S, tid == 0 && ch < 3, 227 + 4 * ch);
       __syncthreads();   // S2: the image may be overwritten
       RES_STAMP(S, tid == 0 && ch < 3, 228 + 4 * ch);
@@ -980,7 +980,13 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 }
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
-template <int T, bool MP>
+// ROLE 0: the one service wave of a workgroup (N + 14 <= 64 lanes: a lane per feature and 14 body lanes).  More features than
+// that split the roles over TWO service waves: ROLE 1 = the feature lanes (and everything a single service wave does besides:
+// dynamics, prediction, result codes, the state store), ROLE 2 = the 14 body lanes on a wave of their own.  The body wave
+// receives each measurement's {Hb, residual, S^-1, gate} from the feature wave through an LDS mailbox (polled: the feature
+// wave never waits for the body wave other than at the barriers); each wave writes the gain rows and the NaN-guard word of
+// its own rows.
+template <int T, bool MP, int ROLE = 0>
 __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane, int nww,
                                             const double* __restrict__ u_all, const double* __restrict__ dt_all,
                                             int* __restrict__ result_all) {
@@ -990,6 +996,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   double* sm = S.sm;
   unsigned flag = 0;
   const bool partial = prm.use_partial_update != 0;
+  constexpr bool PRIMARY = ROLE != 2;
   int par = 0;
   // the per-update critical path runs on this wave: let it win the issue arbitration against its SIMD-mate worker wave
   __builtin_amdgcn_s_setprio(3);
@@ -1019,7 +1026,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dtk, xs, S.ctx, S.Z, S.phiff);
     RES_STAMP(S, lane == 0, 4);
   };
-  if (S.do_prop) { dyn_body(0); dyn_feat(dt); }
+  if (S.do_prop && PRIMARY) { dyn_body(0); dyn_feat(dt); }
   __syncthreads();  // B0
   RES_STAMP(S, lane == 0, 1);
 
@@ -1031,7 +1038,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     __syncthreads();  // B2p
     __syncthreads();  // B2q
     RES_STAMP(S, lane == 0, 5);
-    if (lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
+    if (PRIMARY && lane == 63) {   // body state step (every feature lane has consumed the old body state through ctx)
       double dxb[16], xo[17];
 #pragma unroll
       for (int i = 0; i < 16; i++) dxb[i] = S.xdb[i] * dt;
@@ -1039,8 +1046,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
 #pragma unroll
       for (int i = 0; i < 17; i++) xs[i] = xo[i];
     }
-    if (lane == 0) sm[40 + par] = 0.0;
-    for (int f = lane; f < len; f += 64)   // fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
+    if (PRIMARY && lane == 0) sm[40 + par] = 0.0;
+    for (int f = lane; PRIMARY && f < len; f += 64)   // fix_depth (vi_ekf.cpp:311): state here, covariance through the mailbox
       res_fix_depth(xs + xZ + 5 * f, a.dp, &S.fixadd[par * N + f], &S.fixset[par * N + f], &sm[40 + par], &flag);
     par ^= 1;
     RES_STAMP(S, lane == 0, 6);
@@ -1051,16 +1058,16 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     // A_v G_b, xdot, ctx) is read again before the next B1p; the feature part writes Z rows and Phi_ff, which the workers
     // are still reading: it runs after B4p.
     double dt_next = 0.0;
-    if (MP && kp + 1 < nkp) {
+    if (PRIMARY && MP && kp + 1 < nkp) {
       dt_next = dt_all[(long)(kp + 1) * S.B + S.b];
       dyn_body(kp + 1);
     }
     // One propagate per launch: this wave takes the body strips and the body block of P+ (res_prop_body: they need V, D, Xi,
     // ready since B3p, and write what no contraction reads) off the workers' path instead of waiting for them.
-    if (!MP) res_prop_body<64>(a, S, lane);
+    if (PRIMARY && !MP) res_prop_body<64>(a, S, lane);
     __syncthreads();  // B4p (workers finish the contraction and publish the new body columns / block)
     RES_STAMP(S, lane == 0, 8);
-    if (MP && kp + 1 < nkp) {
+    if (PRIMARY && MP && kp + 1 < nkp) {
       dt = dt_next;
       if (lane == 0) sm[42] = dt;
       dyn_feat(dt);
@@ -1072,17 +1079,18 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   //   lane N+j, j = 0..5   : body row j            (p, v)          linear state x[j]
   //   lane N+6             : body rows 6,7,8       (attitude)      quaternion x[6..9], right-multiplied
   //   lane N+j, j = 7..13  : body row j+2 = 9..15  (b_a, b_g, mu)  linear state x[j+3]
-  const int jb = lane - N;
-  const bool isfeat = lane < N;
+  const int jb = (ROLE == 2) ? lane : ((ROLE == 1) ? -1 : lane - N);
+  const bool isfeat = PRIMARY && lane < N;
   const bool isatt = jb == 6;
   const bool hasq = (isfeat && lane < len) || isatt;
   const bool haslin = (isfeat && lane < len) || (jb >= 0 && jb < 14 && jb != 6);
   int rid0, rid1, rid2;
   if (isfeat) { rid0 = 16 + 3 * lane; rid1 = rid0 + 1; rid2 = rid0 + 2; }
   else if (isatt) { rid0 = 6; rid1 = 7; rid2 = 8; }
-  else { const int r = (jb < 6) ? jb : ((jb < 14) ? jb + 2 : 0); rid0 = rid1 = rid2 = r; }
+  else { const int r = (jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 2 : 0)); rid0 = rid1 = rid2 = r; }
+  const bool rowlane = isfeat || (jb >= 0 && jb < 14);   // this lane owns rows of K / W (the others only tag along)
   double* qptr = isfeat ? (xs + xZ + 5 * lane) : (xs + xATT);
-  double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0)));
+  double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0))));
   const double rho_reset = 1.0 / (2.0 * prm.min_depth);
   const double lam0 = partial ? S.lam[rid0] : 1.0, lam1 = partial ? S.lam[rid1] : 1.0, lam2 = partial ? S.lam[rid2] : 1.0;
   // Lambda of the zeta-zeta 2x2 block (lambda_feat[0], lambda_feat[1])
@@ -1155,14 +1163,17 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       const double w0 = pr[u].x * q.h0 + pr[u].y * q.h1, w1 = pr[u].x * q.h2 + pr[u].y * q.h3;
       const double k0 = w0 * q.s0 + w1 * q.s2, k1 = w0 * q.s1 + w1 * q.s3;
       wv[u] = make_double2(w0, w1); kv[u] = make_double2(k0, k1);
-      if (u == 0 || three) {
+      if (rowlane && (u == 0 || three)) {
         *reinterpret_cast<double2*>(Wd + 2 * ridv[u]) = wv[u];
         *reinterpret_cast<double2*>(Kd + 2 * ridv[u]) = kv[u];
       }
-      if (k0 != k0 || k1 != k1) bad = 1;
+      if (rowlane && (k0 != k0 || k1 != k1)) bad = 1;
     }
     bad = __any(bad);
-    if (lane == 0) { sm[nanword] = bad ? 1.0 : 0.0; sm[gateword] = q.gate; }
+    if (lane == 0) {   // (two service waves: each its own NaN word, 8 apart; the gate verdict is the feature wave's to publish)
+      sm[nanword + (ROLE == 2 ? 8 : 0)] = bad ? 1.0 : 0.0;
+      if (PRIMARY) sm[gateword] = q.gate;
+    }
     o.kA = kv[0]; o.wA = wv[0]; o.kB = kv[1]; o.wB = wv[1]; o.kC = kv[2]; o.bad = bad;
   };
   // This lane's rows of the NEXT measurement's column pair: published by the worker waves one phase ago (buffer `rb`), as they
@@ -1194,12 +1205,35 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     one(0);
     if (three) { one(1); one(2); }
     else { o[1] = o[0]; o[2] = o[0]; }
-    if (lane == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
+    if (isfeat && lane == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
+  };
+  // two service waves: the measurement's uniform values cross from the feature wave to the body wave through sm[16 mb ..],
+  // published by a sequence number in sm[32 + mb] (an int; each mailbox sees increasing numbers)
+  auto send = [&](const Meas& q, int mb, int seq) {
+    if (lane == 0) {
+      double* d = sm + 16 * mb;
+      d[0] = q.h0; d[1] = q.h1; d[2] = q.h2; d[3] = q.h3; d[4] = q.r0; d[5] = q.r1;
+      d[6] = q.s0; d[7] = q.s1; d[8] = q.s2; d[9] = q.s3; d[10] = q.gate;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *(lds_vint_t*)(sm + 32 + mb) = seq;
+  };
+  auto recv = [&](Meas& q, int mb, int seq) {
+    lds_vint_t* w = (lds_vint_t*)(sm + 32 + mb);
+    int spins = 0;
+    while (*w != seq && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); spins++; }
+    if (spins >= (1 << 22)) flag |= FLAG_INTERNAL;   // (a bounded wait that gives up must say so)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double* d = sm + 16 * mb;
+    q.h0 = d[0]; q.h1 = d[1]; q.h2 = d[2]; q.h3 = d[3]; q.r0 = d[4]; q.r1 = d[5];
+    q.s0 = d[6]; q.s1 = d[7]; q.s2 = d[8]; q.s3 = d[9]; q.gate = d[10];
   };
   Meas cur = {}, nxt = {};
   Rows crow = {}, nrow = {};
   if (m < M) {
-    predict(f1, f2, fz, m, __builtin_amdgcn_readfirstlane(S.mslot[m]), cur);
+    if (PRIMARY) predict(f1, f2, fz, m, __builtin_amdgcn_readfirstlane(S.mslot[m]), cur);
+    if (ROLE == 1) send(cur, 0, 1);
+    if (ROLE == 2) recv(cur, 0, 1);
     double2 pr0[3];
 #pragma unroll
     for (int u = 0; u < 3; u++) pr0[u] = lds_ld2(S.Praw + 2 * ridv[u]);   // (the first raw columns: buffer 0, published before Bp)
@@ -1217,7 +1251,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const double2 kA = crow.kA, wA = crow.wA, kB = crow.kB, wB = crow.wB, kC = crow.kC;   // (own rows: from registers)
     sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
     const bool gated = cur.gate != 0.0;
-    const bool bad = crow.bad != 0;      // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows
+    // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows (two service waves: the other one's rows too)
+    const bool bad = crow.bad != 0 || (ROLE != 0 && sm[44 + cnt % 3 + (ROLE == 2 ? 0 : 8)] != 0.0);
     const double r0 = cur.r0, r1 = cur.r1;
     double2 prn[3] = {};
     if (slot_next >= 0) {
@@ -1259,7 +1294,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
-    if (lane == 0) sm[40 + par] = 0.0;
+    if (PRIMARY && lane == 0) sm[40 + par] = 0.0;
     // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238): almost never fires -- one wave-wide test
     const bool odd_depth = !gated && isfeat && lane < len && !(lin >= 0.0 && lin <= 1e2);
     if (__any(odd_depth)) {
@@ -1281,8 +1316,12 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       }
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 2);
-    if (slot_next >= 0) predict(f1, f2, fz, mnext, __builtin_amdgcn_readfirstlane(slot_next), nxt);   // next measurement, from registers
-    if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
+    if (slot_next >= 0) {   // next measurement, from registers
+      if (PRIMARY) predict(f1, f2, fz, mnext, __builtin_amdgcn_readfirstlane(slot_next), nxt);
+      if (ROLE == 1) send(nxt, (cnt + 1) & 1, cnt + 2);
+      if (ROLE == 2) recv(nxt, (cnt + 1) & 1, cnt + 2);
+    }
+    if (PRIMARY && result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
     if (slot_next >= 0) gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), prn, (cnt & 1) ? S.Kt : S.Z, nrow);
     {   // this wave's share of the body-column sweep of measurement m (few worker waves only), after its chain
@@ -1309,7 +1348,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // ---------------- store x, status ----------------
   double* xg = a.x_out + (long)S.b * a.nxs;
   const int xend = (a.x_out != a.x) ? a.nxs : xZ + 5 * len;   // another ring slot gets the whole vector (zeros past the features)
-  for (int i = lane; i < xend; i += 64) {
+  for (int i = lane; PRIMARY && i < xend; i += 64) {
     const double v = xs[i];
     if (v != v) flag |= FLAG_NAN;
     if (v > 1e6) flag |= FLAG_BLOWUP;
@@ -1356,7 +1395,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
       const double lk = a.lambda[tid & 15], lq = a.lambda[16 + (tid >> 4)];
       S.Lbc[tid] = a.dp->use_partial_update ? (lk + lq - lq * lk) : 1.0;
     }
-    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; }
+    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; S.sm[32] = 0.0; S.sm[33] = 0.0; S.sm[52] = 0.0; S.sm[53] = 0.0; S.sm[54] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
       const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];
@@ -1382,8 +1421,8 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   RES_STAMP(S, tid == 0, 63);
 }
 
-template <int RB, int NW, bool MP = false>
-__global__ __launch_bounds__((NW + 1) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
+template <int RB, int NW, bool MP = false, int NS = 1>
+__global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
                                                                 const double* __restrict__ z_all,
@@ -1391,18 +1430,24 @@ __global__ __launch_bounds__((NW + 1) * 64, (NW <= 3) ? 2 : 1) void k_step_resid
                                                                 const double* __restrict__ R_all, long r_stride_b,
                                                                 long r_stride_m, int* __restrict__ result_all) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int T = (NW + 1) * 64, TW = NW * 64;
+  constexpr int T = (NW + NS) * 64, TW = NW * 64;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.B) return;
   ResShared S;
   res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
   // The service wave's chain is the floor of an update, so it should not share its SIMD's issue slots with a worker wave.  A
-  // workgroup's waves go to the four SIMDs round-robin: with 7 waves (NW = 6) the 4th one is alone on its SIMD -- that is
-  // the service wave.  With 8 waves (NW = 7) every SIMD holds two and the last wave serves.
-  constexpr int SVC = (NW == 6) ? 3 : NW;
+  // workgroup's waves go to the four SIMDs round-robin: with 7 waves (NW = 6, one service wave) the 4th one is alone on its
+  // SIMD -- that is the service wave.  Otherwise the last wave(s) serve.
+  constexpr int SVC = (NW == 6 && NS == 1) ? 3 : NW;
   const int wave = tid >> 6;
-  if (wave == SVC) res_service<T, MP>(a, S, tid & 63, NW, u_all, dt_all, result_all);
-  else res_worker<RB, TW, MP>(a, S, tid - (wave > SVC ? 64 : 0));
+  if (NS == 2) {
+    if (wave == NW) res_service<T, MP, 1>(a, S, tid & 63, NW, u_all, dt_all, result_all);
+    else if (wave == NW + 1) res_service<T, MP, 2>(a, S, tid & 63, NW, u_all, dt_all, result_all);
+    else res_worker<RB, TW, MP, T>(a, S, tid);
+  } else {
+    if (wave == SVC) res_service<T, MP>(a, S, tid & 63, NW, u_all, dt_all, result_all);
+    else res_worker<RB, TW, MP, T>(a, S, tid - (wave > SVC ? 64 : 0));
+  }
 }
 
 }  // namespace viekf
