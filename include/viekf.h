@@ -186,6 +186,16 @@ int viekf_batch_restore(viekf_batch *b, int32_t slot);
  * P_[ip] written from x_[i_], P_[i_]) and which then selects dst: the fused kernel reads P from the old slot and stores
  * it into the new one, so keeping the history costs no extra pass over P.  The feature counts are not part of a slot. */
 int viekf_batch_select(viekf_batch *b, int32_t slot);
+/* Filters on INDEPENDENT clocks in one batch (one filter per rosbag / trajectory): a participation mask and per-filter ring slots.
+ * set_active: mask [batch] (NULL = everybody again): filters with mask[b] == 0 take no part in the following viekf_batch_propagate /
+ * _update_feat / _step / _step_n launches -- their state is not touched (the reference's filters are separate objects,
+ * include/vi_ekf.h:82: one propagates while another does not).  snapshot_filters / restore_filters: the ring copies of
+ * viekf_batch_snapshot / _restore with a slot PER FILTER, slot [batch], < 0 = that filter is skipped: every filter rewinds to and
+ * records at its own ring position (src/vi_ekf/vi_ekf_meas.cpp:45-63 per filter).  Both need the live state in the batch's own
+ * buffers (no viekf_batch_select). */
+int viekf_batch_set_active(viekf_batch *b, const uint8_t *mask, viekf_mem where);
+int viekf_batch_snapshot_filters(viekf_batch *b, const int32_t *slot, viekf_mem where);
+int viekf_batch_restore_filters(viekf_batch *b, const int32_t *slot, viekf_mem where);
 int viekf_batch_propagate_to(viekf_batch *b, const double *u, const double *dt, int32_t dst_slot, viekf_mem where);
 
 /* ONE measurement of any model of the reference's table per filter: VIEKF::update with
@@ -226,6 +236,20 @@ int viekf_batch_step_n(viekf_batch *b, int32_t K, const double *u, const double 
  * all filters queue the same entries. */
 typedef struct viekf_seq viekf_seq;
 int viekf_seq_create(viekf_batch *core, int32_t state_hist, int32_t meas_hist, viekf_seq **out);
+/* INDEPENDENT CLOCKS: the filters of the batch are fed from different sources (one rosbag / trajectory each: different time
+ * stamps, different camera delays) and still share the batch.  Every filter keeps its own time ring, input queue and measurement
+ * queue and makes its own handle_measurements decisions (deferral, rewind target, replay length: src/vi_ekf/vi_ekf_meas.cpp:6-127
+ * per filter); the device steps of a call are batched over the filters that take the same kind of step (viekf_batch_set_active,
+ * viekf_batch_restore_filters / _snapshot_filters).  Each filter's results are those of a batch of one fed the same inputs.  The
+ * state history is a snapshot ring here (one copy of (x, P) per propagate, not the zero-copy ring of the shared clock).
+ *   viekf_seq_propagate_t / _add_measurement_t take t [batch] and an optional mask [batch] (0 = this filter has no sample in
+ *   this call); viekf_seq_propagate / _add_measurement with one t still work (same stamp for everybody); everything else
+ *   (handle_measurements, keep_only_features, init_feature, global pose) is shared.  The log writer is lock-step only. */
+int viekf_seq_create_independent(viekf_batch *core, int32_t state_hist, int32_t meas_hist, viekf_seq **out);
+int viekf_seq_propagate_t(viekf_seq *s, const double *u /* [batch][6] */, const double *t /* [batch] */, const uint8_t *mask);
+int viekf_seq_add_measurement_t(viekf_seq *s, const double *t /* [batch] */, int32_t type, const double *z, int32_t zdim,
+                                const double *R, int32_t rdim, int32_t active, const int32_t *id, const double *depth,
+                                const uint8_t *mask, int32_t *result);
 int viekf_seq_destroy(viekf_seq *s);
 int viekf_seq_propagate(viekf_seq *s, const double *u /* [batch][6] */, double t);
 /* z [batch][zdim]; R rdim x rdim column-major, shared; id [batch] global feature id (NULL = -1); depth [batch] (NULL = NaN);

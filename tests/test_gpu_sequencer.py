@@ -204,3 +204,93 @@ def test_global_pose_and_covariance_through_keyframe_resets(tmp_path):
     ref = np.stack([np.concatenate([[r["t"]], r["gpose"]]) for r in os_[lf].rec["state"]])
     assert_close(gp, ref, "global_pose.log through resets")
     assert np.abs(ref[-1, 1:4] - os_[lf].rec["state"][-1]["x"][0:3]).max() > 1e-6   # global != node-relative by now
+
+
+def _feed(sg, sel, B, N, seed, clock0, dt_imu, delay, steps, alt_every=0):
+    """one source (rosbag) per filter: its own clock origin, IMU period and camera delay.  `sel` = the filters of the batch
+    this source feeds (all others are masked out of its calls); returns nothing -- the sequencer holds the state"""
+    rng = np.random.default_rng(seed)
+    pix = rng.uniform(120, 480, (N, 2))
+    R = np.eye(2) * 10.0
+    mask = np.zeros(B, dtype=np.uint8)
+    mask[sel] = 1
+    ind = getattr(sg, "independent", False)
+    tt = (lambda t: np.full(B, t)) if ind else (lambda t: t)     # (a lock-step sequencer takes the shared stamp)
+    if not ind:
+        mask = None
+    for k in range(steps):
+        t = clock0 + dt_imu * k
+        u1 = np.array([0.1, -0.05, -9.80665, 0.01, 0.0, 0.02]) + rng.normal(0, 0.3, 6) * np.array([1, 1, 1, .05, .05, .05])
+        u = np.zeros((B, 6))
+        u[sel] = u1
+        yield ("imu", k)
+        sg.propagate_state(u, tt(t), mask=mask)
+        if k % 7 == 3:
+            tz = t - delay
+            for i in range(N):
+                z = np.zeros((B, 2))
+                z[sel] = pix[i] + rng.normal(0, 0.5, 2)
+                sg.add_measurement(tt(tz), z, orc.FEAT, R, True, id=i, mask=mask)
+            if alt_every and k % alt_every == 3:
+                alt = np.zeros((B, 1))
+                alt[sel] = rng.normal(2.0, 0.05)
+                sg.add_measurement(tt(tz + 0.001), alt, orc.ALT, np.array([[0.01]]), True, mask=mask)
+            yield ("frame", k)
+
+
+@pytest.mark.gpu
+def test_independent_clocks_equal_separate_filters_bit_for_bit():
+    """Filters fed from different sources share a batch (north_star: one filter per trajectory / rosbag): different clock
+    origins, IMU periods and camera delays (0 and 30 ms) -- per-filter deferral, rewind target and replay length
+    (vi_ekf_meas.cpp:6-127 per filter).  Each filter must equal, bit for bit, a batch of one fed the same source."""
+    import vi_ekf_amd as v
+    N, steps = 5, 48
+    p = dict(_params(0), keyframe_overlap_threshold=0.8, name="ind")
+    sources = [dict(seed=31, clock0=0.0, dt_imu=0.004, delay=0.0, alt_every=14),
+               dict(seed=32, clock0=1000.0, dt_imu=0.005, delay=0.03, alt_every=0),
+               dict(seed=33, clock0=-50.0, dt_imu=0.004, delay=0.0105, alt_every=7)]
+    B = len(sources)
+    # together: one batch, the sources interleaved call by call (each call carries one source's sample, the others masked out)
+    g = v.BatchVIEKF(B, N, p)
+    sg = v.SeqVIEKF(g, state_hist=64, meas_hist=200, independent=True)
+    gens = [_feed(sg, [b], B, N, steps=steps, **src) for b, src in enumerate(sources)]
+    live = list(range(B))
+    while live:
+        for b in list(live):
+            try:
+                ev = next(gens[b])
+                if ev[0] == "frame":
+                    sg.handle_measurements()     # (every filter with queued work takes its own steps)
+            except StopIteration:
+                live.remove(b)
+    x_all, P_all = g.get_state(), g.get_covariance()
+    tracked = sg.tracked_features()
+    # apart: a batch of one per source, same sequencer mode
+    for b, src in enumerate(sources):
+        g1 = v.BatchVIEKF(1, N, p)
+        s1 = v.SeqVIEKF(g1, state_hist=64, meas_hist=200, independent=True)
+        for ev in _feed(s1, [0], 1, N, steps=steps, **src):
+            if ev[0] == "frame":
+                s1.handle_measurements()
+        assert np.array_equal(g1.get_state()[0], x_all[b]), "filter %d: state differs from its own batch of one" % b
+        assert np.array_equal(g1.get_covariance()[0], P_all[b]), "filter %d: covariance differs" % b
+        assert s1.tracked_features()[0] == tracked[b]
+        # ... and the independent-clock plumbing equals the restated reference plumbing fed the same source
+        o = so.SeqOracle(orc.OracleFilter(N).init(**_params(0)), 0.8, state_hist=64)
+        rng = np.random.default_rng(src["seed"])
+        pix = rng.uniform(120, 480, (N, 2))
+        for k in range(steps):
+            t = src["clock0"] + src["dt_imu"] * k
+            u1 = np.array([0.1, -0.05, -9.80665, 0.01, 0.0, 0.02]) + rng.normal(0, 0.3, 6) * np.array([1, 1, 1, .05, .05, .05])
+            o.propagate_state(u1, t)
+            if k % 7 == 3:
+                tz = t - src["delay"]
+                for i in range(N):
+                    o.add_measurement(tz, pix[i] + rng.normal(0, 0.5, 2), orc.FEAT, np.eye(2) * 10.0, True, i, float("nan"))
+                if src["alt_every"] and k % src["alt_every"] == 3:
+                    o.add_measurement(tz + 0.001, np.array([rng.normal(2.0, 0.05)]), orc.ALT, np.array([[0.01]]), True)
+                o.handle_measurements()
+        assert not o.log, o.log
+        assert_close(x_all[b], o.f.x, "filter %d vs restated plumbing: x" % b)
+        assert_close(P_all[b], o.f.P, "filter %d vs restated plumbing: P" % b)
+    assert np.abs(x_all[0] - x_all[1]).max() > 1e-6   # (the sources really differ)

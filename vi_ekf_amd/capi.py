@@ -27,7 +27,8 @@ SYMBOLS = [
     "viekf_seq_handle_measurements", "viekf_seq_keep_only_features", "viekf_seq_tracked_features", "viekf_seq_status",
     "viekf_batch_eval_xdot", "viekf_batch_eval_h", "viekf_batch_get_cov_diag", "viekf_seq_init_logger",
     "viekf_seq_disable_logger", "viekf_batch_step_n", "viekf_batch_get_cov_block", "viekf_seq_get_global_pose",
-    "viekf_seq_get_global_cov", "viekf_seq_init_feature",
+    "viekf_seq_get_global_cov", "viekf_seq_init_feature", "viekf_batch_set_active", "viekf_batch_snapshot_filters",
+    "viekf_batch_restore_filters", "viekf_seq_create_independent", "viekf_seq_propagate_t", "viekf_seq_add_measurement_t",
 ]
 
 

@@ -60,6 +60,9 @@ struct viekf_batch {
   double *home_x = nullptr, *home_P = nullptr;   // the batch's own buffers (live state while live_slot < 0)
   double *h_x = nullptr, *h_P = nullptr;
   int* h_len = nullptr;
+  unsigned char* d_active = nullptr;   // [B] participation mask of the next propagate / feature-update launches (NULL: all)
+  bool active_on = false;
+  int* d_ringslot = nullptr;           // [B] staging of per-filter ring slots (viekf_batch_snapshot_filters / _restore_filters)
 };
 
 namespace {
@@ -72,6 +75,7 @@ StreamArgs make_args(const viekf_batch* b) {
   a.ws_stride = b->ws_stride;
   a.dp = b->d_dp;
   a.x_out = b->d_x; a.P_out = b->d_P;
+  a.active = b->active_on ? b->d_active : nullptr;
   return a;
 }
 
@@ -450,7 +454,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len};
+  void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_active, b->d_ringslot};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -851,6 +855,43 @@ static int history_copy(viekf_batch* b, int32_t slot, bool save) {
 }
 int viekf_batch_snapshot(viekf_batch* b, int32_t slot) { return history_copy(b, slot, true); }
 int viekf_batch_restore(viekf_batch* b, int32_t slot) { return history_copy(b, slot, false); }
+
+int viekf_batch_set_active(viekf_batch* b, const uint8_t* mask, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  if (!mask) { b->active_on = false; return VIEKF_OK; }
+  if (!b->d_active) HIP_TRY(hipMalloc(&b->d_active, (size_t)b->B));
+  HIP_TRY(hipMemcpyAsync(b->d_active, mask, (size_t)b->B, where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                         b->stream));
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));   // (the caller's buffer may go away)
+  b->active_on = true;
+  return VIEKF_OK;
+}
+
+static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, int to_ring) {
+  if (int rc = check_batch(b)) return rc;
+  if (!slot) return fail(VIEKF_ERR_INVALID, "slot is null");
+  if (b->hist_depth <= 0) return fail(VIEKF_ERR_INVALID, "no history ring (viekf_batch_history_resize first)");
+  if (b->live_slot >= 0) return fail(VIEKF_ERR_INVALID, "per-filter ring copies need the live state in the batch's own buffers (viekf_batch_select(-1))");
+  HIP_TRY(hipSetDevice(b->device));
+  if (int rc = ensure_full_P(b)) return rc;
+  if (where == VIEKF_HOST)
+    for (int i = 0; i < b->B; i++)
+      if (slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
+  const int* d_slot = slot;
+  if (where == VIEKF_HOST) {
+    if (!b->d_ringslot) HIP_TRY(hipMalloc(&b->d_ringslot, sizeof(int) * (size_t)b->B));
+    HIP_TRY(hipMemcpyAsync(b->d_ringslot, slot, sizeof(int) * (size_t)b->B, hipMemcpyHostToDevice, b->stream));
+    d_slot = b->d_ringslot;
+  }
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->h_x, b->h_P, d_slot, to_ring);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+int viekf_batch_snapshot_filters(viekf_batch* b, const int32_t* slot, viekf_mem where) { return ring_filters(b, slot, where, 1); }
+int viekf_batch_restore_filters(viekf_batch* b, const int32_t* slot, viekf_mem where) { return ring_filters(b, slot, where, 0); }
 
 int viekf_batch_select(viekf_batch* b, int32_t slot) {
   if (int rc = check_batch(b)) return rc;

@@ -1433,6 +1433,7 @@ __global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resi
   constexpr int T = (NW + NS) * 64, TW = NW * 64;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.B) return;
+  if (a.active && !a.active[blockIdx.x]) return;   // (the whole workgroup: before any barrier)
   ResShared S;
   res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
   // The service wave's chain is the floor of an update, so it should not share its SIMD's issue slots with a worker wave.  A

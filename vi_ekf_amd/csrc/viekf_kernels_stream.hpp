@@ -28,6 +28,8 @@ struct StreamArgs {
   const DevParams* dp;  // device memory (uniform loads); NOT by value: indexing a by-value kernarg array spills it to scratch
   double* x_out;        // where the fused-step kernel stores the state / covariance: the same buffers (in place) or another
   double* P_out;        // slot of the history ring (viekf_batch_propagate_to: the propagate writes the NEXT slot, no copy)
+  const unsigned char* active;   // [B] or NULL: filters with active[b] == 0 take no part in a propagate / feature-update launch
+                                 // (viekf_batch_set_active: filters on different clocks share a batch)
 };
 
 constexpr int WK = 40;   // contraction depth of the low-rank part (16 + 16 + 6, padded to whole MFMA k-steps of 4)
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.B) return;
+  if (a.active && !a.active[b]) return;
   const int n = a.n, ld = a.ld;
   double* xs = smem;                    // [nxs]
   double* Abb = xs + a.nxs;             // 16x16 row-major
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.B) return;
+  if (a.active && !a.active[b]) return;
   const int n = a.n, ld = a.ld;
   double* xs = smem;           // [nxs]
   double* W = xs + a.nxs;      // [n][2]
@@ -616,6 +620,7 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.B) return;
+  if (a.active && !a.active[b]) return;
   const int n = a.n, ld = a.ld;
   constexpr int BLD = 2 * BG + 2, BWIN = 2 * BG;
   const BlkLds L(a.N, n, a.nxs, BG);
@@ -1143,6 +1148,26 @@ __global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
 __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
   const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
+}
+
+// per-filter history: copies (x, P) of filter b between the batch's live buffers and ring slot slot[b] (< 0: filter skipped);
+// to_ring != 0: live -> ring.  Filters on independent clocks advance and rewind their rings separately (viekf_seq, independent
+// mode); the feature counts are not part of a slot, as in the reference's ring (include/vi_ekf.h:156-160).
+__global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restrict__ ring_x, double* __restrict__ ring_P,
+                                                   const int* __restrict__ slot, int to_ring) {
+  const int b = blockIdx.x;
+  if (b >= a.B) return;
+  const int sl = slot[b];
+  if (sl < 0) return;
+  const long nP = (long)a.n * a.ld;
+  double* lx = a.x + (long)b * a.nxs;
+  double* lP = a.P + (long)b * nP;
+  double* rx = ring_x + ((long)sl * a.B + b) * a.nxs;
+  double* rP = ring_P + ((long)sl * a.B + b) * nP;
+  const double2* src = reinterpret_cast<const double2*>(to_ring ? lP : rP);   // (ld is even and the buffers 16-byte aligned)
+  double2* dst = reinterpret_cast<double2*>(to_ring ? rP : lP);
+  for (long e = threadIdx.x; e < nP / 2; e += 256) dst[e] = src[e];
+  for (int e = threadIdx.x; e < a.nxs; e += 256) (to_ring ? rx : lx)[e] = (to_ring ? lx : rx)[e];
 }
 
 // a rectangular block P[r0 .. r0+nr, c0 .. c0+nc) of every filter -> out [B][nc][nr] (column-major per filter)

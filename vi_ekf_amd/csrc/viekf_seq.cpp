@@ -88,8 +88,35 @@ void add_adj_cov(const double* T, const double* C, double* out) {
 
 }  // namespace
 
+// Independent clocks (viekf_seq_create_independent): every filter keeps its own time ring, input deque and measurement queue
+// -- the reference class's members, one set per filter -- and the device work of a call is batched over the filters that
+// take the same kind of step.
+struct FMeas {                        // measurement_t, include/vi_ekf.h:167-179 (one filter)
+  double t;
+  int type, zdim, rdim;
+  double z[4], R[9];
+  bool active;
+  int32_t id;
+  bool handled;
+};
+struct FilterSeq {
+  std::vector<double> t;                                           // t_ ring
+  int i = 0;                                                       // i_
+  double start_t = NAN;
+  std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [6]), newest first
+  std::deque<FMeas> zbuf;                                          // newest first
+};
+struct SeqOp {                        // one device step of one filter's handle_measurements, in the order it must run
+  enum Kind { REWIND, PROP, FEAT_FRAME, GENERIC } kind;
+  int slot = -1;                      // REWIND: ring slot to restore;  PROP: ring slot to record into
+  double u[6] = {}, dt = 0.0;         // PROP
+  std::vector<FMeas> meas;            // FEAT_FRAME: the frame's entries in processing order;  GENERIC: one entry
+};
+
 struct viekf_seq {
   viekf_batch* core = nullptr;
+  bool indep = false;                                              // independent clocks
+  std::vector<FilterSeq> fs;
   int B = 0, N = 0, H = 0, MH = 0;
   viekf_params prm;
   std::vector<double> t;                                           // t_ ring
@@ -268,6 +295,226 @@ int update_frame(viekf_seq* s, long zi, int k, std::vector<int32_t>& res) {
   return viekf_batch_update_feat(s->core, z.data(), slot.data(), k, s->zbuf[zi].R.data(), 0, res.data(), VIEKF_HOST);
 }
 
+// ---- independent clocks --------------------------------------------------------------------------------------------------
+// propagate_state's bookkeeping for ONE filter (vi_ekf.cpp:262-318); returns true and the interval if the numeric core is to
+// run -- the caller batches those -- and advances the filter's ring position then.
+bool plan_propagate(viekf_seq* s, int b, const double* u_in, double t, bool save_input, double* dt_out, int* dst_slot) {
+  FilterSeq& f = s->fs[b];
+  if (save_input) {
+    std::vector<double> ub(6);
+    rota(s->prm.q_b_u, u_in, ub.data());
+    rota(s->prm.q_b_u, u_in + 3, ub.data() + 3);
+    f.u.emplace_front(t, std::move(ub));                           // :269-272 (the ROTATED input is stored)
+  }
+  if (std::isnan(f.start_t)) { f.start_t = t; f.t[f.i] = t; return false; }   // :274-279
+  const double dt = t - f.t[f.i];
+  if (std::fabs(dt) < 1e-6 || dt < 0) return false;                // :281-289
+  const int ip = (f.i + 1) % s->H;                                 // :298
+  f.i = ip;                                                        // :306
+  f.t[ip] = t;
+  *dt_out = dt;
+  *dst_slot = ip;
+  return true;
+}
+
+// handle_measurements of ONE filter (vi_ekf_meas.cpp:6-127) as a list of device steps; the host bookkeeping (ring position,
+// times, handled flags, queue trims) is done here, the steps run afterwards, batched over the filters
+void plan_handle(viekf_seq* s, int b, std::vector<SeqOp>& ops) {
+  FilterSeq& f = s->fs[b];
+  auto prop = [&](const std::vector<double>& ur, double t) {       // propagate_state(u, t, false): replays are not stored again
+    SeqOp op;
+    op.kind = SeqOp::PROP;
+    if (plan_propagate(s, b, ur.data(), t, false, &op.dt, &op.slot)) {
+      std::memcpy(op.u, ur.data(), sizeof op.u);
+      ops.push_back(std::move(op));
+    }
+  };
+  if (f.zbuf.empty() || f.u.empty()) return;                       // :12-13
+  long zi = (long)f.zbuf.size() - 1;                               // :16-18 oldest unhandled
+  while (f.zbuf[zi].handled && zi != 0) zi--;
+  if (zi == 0 && f.zbuf[zi].handled) return;                       // :21-22
+  if (f.zbuf[zi].t > f.u[0].first) return;                         // :24-28 from the future
+  size_t ui = 0;                                                   // :32-38 input just before the measurement
+  while (ui != f.u.size()) {
+    if (f.zbuf[zi].t > f.u[ui].first) break;
+    ui++;
+  }
+  if (ui == f.u.size() || f.zbuf[zi].t <= f.u[ui].first) return;   // :39-43 not enough input history
+  int k = s->H, target = -1;                                       // :46-57 rewind
+  while (k > 0) {
+    const int j = (f.i + k) % s->H;
+    if (f.t[j] <= f.u[ui].first) { target = j; break; }
+    k--;
+  }
+  if (k == 0) { f.zbuf.erase(f.zbuf.begin() + zi); return; }       // :59-64 not enough state history
+  if (target != f.i) {
+    SeqOp op;
+    op.kind = SeqOp::REWIND;
+    op.slot = target;
+    ops.push_back(std::move(op));
+    f.i = target;
+  }
+  auto mate = [](const FMeas& a, const FMeas& z) {                 // entries of one camera frame (see update_frame)
+    return !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim &&
+           std::memcmp(a.R, z.R, sizeof(double) * 4) == 0;
+  };
+  ui--;                                                            // :74
+  while (ui != 0) {                                                // :75
+    bool left_inner_by_break = false;
+    while (f.zbuf[zi].t <= f.u[ui].first) {                        // :78
+      FMeas& z = f.zbuf[zi];
+      if (f.t[f.i] < z.t) prop(f.u[ui].second, z.t);               // :81-82
+      if (!z.handled) {                                            // :87-95
+        SeqOp op;
+        long zl = zi;
+        if (z.type == VIEKF_FEAT && z.active)
+          while (zl > 0 && mate(f.zbuf[zl - 1], z)) zl--;
+        op.kind = (z.type == VIEKF_FEAT && z.active) ? SeqOp::FEAT_FRAME : SeqOp::GENERIC;
+        op.slot = f.i;   // an update changes x_[i_], P_[i_] in place (vi_ekf_meas.cpp:254-271): the ring slot is refreshed after it
+        for (long q = zi; q >= zl; q--) { f.zbuf[q].handled = true; op.meas.push_back(f.zbuf[q]); }   // :198
+        ops.push_back(std::move(op));
+        zi = zl;
+      }
+      if (zi != 0) {                                               // :97-105
+        zi--;
+        while (f.u[ui].first < f.zbuf[zi].t && ui != 0) { prop(f.u[ui].second, f.u[ui].first); ui--; }
+      } else {                                                     // :106-115
+        while (ui != 0) { prop(f.u[ui].second, f.u[ui].first); ui--; }
+        left_inner_by_break = true;
+        break;
+      }
+    }
+    if (!left_inner_by_break) break;
+  }
+  prop(f.u[ui].second, f.u[ui].first);                             // :118
+  while ((int)f.zbuf.size() > s->MH) f.zbuf.pop_back();            // :121-122
+  while ((int)f.u.size() > s->H) f.u.pop_back();                   // :125-126
+}
+
+// independent clocks: the reference changes x_[i_], P_[i_] in place (updates, init_feature, clear_feature, keyframe reset), and
+// that slot is what a later rewind finds; here the ring holds copies, so the current slot of the touched filters is refreshed
+int refresh_slots(viekf_seq* s, const std::vector<uint8_t>& touched) {
+  std::vector<int32_t> slot(s->B, -1);
+  bool any = false;
+  for (int b = 0; b < s->B; b++)
+    if (touched[b]) { slot[b] = s->fs[b].i; any = true; }
+  return any ? viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST) : VIEKF_OK;
+}
+
+// runs the planned steps: per round the next step of every filter, one masked launch per kind of step
+int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std::vector<int32_t>>& gated) {
+  const int B = s->B;
+  std::vector<size_t> head(B, 0);
+  std::vector<uint8_t> mask(B);
+  std::vector<int32_t> slot(B);
+  for (;;) {
+    bool any = false;
+    for (int b = 0; b < B; b++) any |= head[b] < ops[b].size();
+    if (!any) break;
+    auto group = [&](SeqOp::Kind k, int gtype) {                   // filters whose next step is of this kind (and type)
+      bool got = false;
+      for (int b = 0; b < B; b++) {
+        const bool in = head[b] < ops[b].size() && ops[b][head[b]].kind == k &&
+                        (k != SeqOp::GENERIC || ops[b][head[b]].meas[0].type == gtype);
+        mask[b] = in ? 1 : 0;
+        got |= in;
+      }
+      return got;
+    };
+    std::vector<uint8_t> done(B, 0);
+    if (group(SeqOp::REWIND, 0)) {
+      for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
+      if (int rc = viekf_batch_restore_filters(s->core, slot.data(), VIEKF_HOST)) return rc;
+      for (int b = 0; b < B; b++) done[b] |= mask[b];
+    }
+    if (group(SeqOp::PROP, 0)) {
+      std::vector<double> u((size_t)B * 6, 0.0), dt(B, 0.0);
+      for (int b = 0; b < B; b++) {
+        if (!mask[b] || done[b]) { mask[b] = 0; continue; }
+        std::memcpy(u.data() + 6 * (size_t)b, ops[b][head[b]].u, sizeof(double) * 6);
+        dt[b] = ops[b][head[b]].dt;
+        slot[b] = ops[b][head[b]].slot;
+      }
+      for (int b = 0; b < B; b++) if (!mask[b]) slot[b] = -1;
+      if (int rc = viekf_batch_set_active(s->core, mask.data(), VIEKF_HOST)) return rc;
+      int rc = viekf_batch_propagate(s->core, u.data(), dt.data(), VIEKF_HOST);
+      (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
+      if (rc) return rc;
+      if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
+      for (int b = 0; b < B; b++) done[b] |= mask[b];
+    }
+    if (group(SeqOp::FEAT_FRAME, 0)) {
+      int M = 0;
+      for (int b = 0; b < B; b++) {
+        if (done[b]) mask[b] = 0;
+        if (mask[b]) M = std::max(M, (int)ops[b][head[b]].meas.size());
+      }
+      if (M > 0) {
+        // R may differ between filters: r_mode 1 (one R per filter)
+        std::vector<double> z((size_t)B * M * 2, 0.0), R((size_t)B * 4, 0.0);
+        std::vector<int32_t> sl((size_t)B * M, -1), res((size_t)B * M, VIEKF_MEAS_SKIPPED);
+        for (int b = 0; b < B; b++) {
+          if (!mask[b]) continue;
+          const SeqOp& op = ops[b][head[b]];
+          std::memcpy(R.data() + 4 * (size_t)b, op.meas[0].R, sizeof(double) * 4);
+          for (size_t j = 0; j < op.meas.size(); j++) {
+            z[((size_t)b * M + j) * 2] = op.meas[j].z[0];
+            z[((size_t)b * M + j) * 2 + 1] = op.meas[j].z[1];
+            sl[(size_t)b * M + j] = local_id(s, b, op.meas[j].id);
+          }
+        }
+        if (int rc = viekf_batch_set_active(s->core, mask.data(), VIEKF_HOST)) return rc;
+        int rc = viekf_batch_update_feat(s->core, z.data(), sl.data(), M, R.data(), 1, res.data(), VIEKF_HOST);
+        (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
+        if (rc) return rc;
+        for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
+        if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
+        for (int b = 0; b < B; b++) {
+          if (!mask[b]) continue;
+          const SeqOp& op = ops[b][head[b]];
+          for (size_t j = 0; j < op.meas.size(); j++)
+            if (res[(size_t)b * M + j] == VIEKF_MEAS_GATED) gated[b].push_back(op.meas[j].id);
+          done[b] = 1;
+        }
+      }
+    }
+    for (int type = 0; type < VIEKF_TOTAL_MEAS; type++) {
+      if (!group(SeqOp::GENERIC, type)) continue;
+      int zdim = 0, rdim = 0;
+      for (int b = 0; b < B; b++) {
+        if (done[b]) mask[b] = 0;
+        if (mask[b]) { zdim = ops[b][head[b]].meas[0].zdim; rdim = ops[b][head[b]].meas[0].rdim; }
+      }
+      if (zdim == 0) continue;
+      std::vector<double> z((size_t)B * zdim, 0.0), R((size_t)B * rdim * rdim, 0.0);
+      std::vector<int32_t> sl(B, -1), res(B, VIEKF_MEAS_SKIPPED);
+      std::vector<uint8_t> act(B, 2);                              // 2 = this filter takes no part
+      const bool needs_slot = type == VIEKF_QZETA || type == VIEKF_FEAT || type == VIEKF_DEPTH || type == VIEKF_INV_DEPTH;
+      for (int b = 0; b < B; b++) {
+        if (!mask[b]) continue;
+        const FMeas& m = ops[b][head[b]].meas[0];
+        if (m.zdim != zdim || m.rdim != rdim) { mask[b] = 0; continue; }   // (a later round takes it)
+        std::memcpy(z.data() + (size_t)b * zdim, m.z, sizeof(double) * zdim);
+        std::memcpy(R.data() + (size_t)b * rdim * rdim, m.R, sizeof(double) * rdim * rdim);
+        if (needs_slot) sl[b] = local_id(s, b, m.id);
+        act[b] = m.active ? 1 : 0;
+      }
+      if (int rc = viekf_batch_update(s->core, type, z.data(), zdim, R.data(), rdim, 1, needs_slot ? sl.data() : nullptr, act.data(),
+                                      res.data(), VIEKF_HOST))
+        return rc;
+      for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
+      if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
+      for (int b = 0; b < B; b++) {
+        if (!mask[b]) continue;
+        if (type == VIEKF_FEAT && res[b] == VIEKF_MEAS_GATED) gated[b].push_back(ops[b][head[b]].meas[0].id);
+        done[b] = 1;
+      }
+    }
+    for (int b = 0; b < B; b++) head[b] += done[b];
+  }
+  return VIEKF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -302,14 +549,107 @@ int viekf_seq_destroy(viekf_seq* s) {
   return VIEKF_OK;
 }
 
+int viekf_seq_create_independent(viekf_batch* core, int32_t state_hist, int32_t meas_hist, viekf_seq** out) {
+  if (!core || !out || state_hist < 2 || meas_hist < 1) return VIEKF_ERR_INVALID;
+  viekf_seq* s = new viekf_seq;
+  s->core = core;
+  s->indep = true;
+  int32_t B, N, nx, n;
+  if (int rc = viekf_batch_dims(core, &B, &N, &nx, &n)) { delete s; return rc; }
+  if (int rc = viekf_batch_get_params(core, &s->prm)) { delete s; return rc; }
+  if (int rc = viekf_batch_history_resize(core, state_hist)) { delete s; return rc; }
+  s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
+  s->fs.resize(B);
+  for (auto& f : s->fs) f.t.assign(state_hist, NAN);               // vi_ekf.cpp:22-27
+  std::vector<int32_t> zero(B, 0);
+  if (int rc = viekf_batch_snapshot_filters(core, zero.data(), VIEKF_HOST)) { delete s; return rc; }   // x_[0], P_[0]
+  s->ids.assign(B, {});
+  s->next_id.assign(B, 0);
+  s->kf_feats.assign(B, {});
+  s->node.assign((size_t)B * 7, 0.0);
+  for (int b = 0; b < B; b++) s->node[7 * (size_t)b + 3] = 1.0;
+  s->node_cov.assign((size_t)B * 36, 0.0);
+  *out = s;
+  return VIEKF_OK;
+}
+
+int viekf_seq_propagate_t(viekf_seq* s, const double* u, const double* t, const uint8_t* mask) {
+  if (!s || !u || !t || !s->indep) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<uint8_t> act(B, 0);
+  std::vector<double> dt(B, 0.0);
+  std::vector<int32_t> slot(B, -1);
+  bool any = false;
+  for (int b = 0; b < B; b++) {
+    if (mask && !mask[b]) continue;
+    if (plan_propagate(s, b, u + 6 * (size_t)b, t[b], true, &dt[b], &slot[b])) { act[b] = 1; any = true; }
+  }
+  if (!any) return VIEKF_OK;
+  if (int rc = viekf_batch_set_active(s->core, act.data(), VIEKF_HOST)) return rc;
+  int rc = viekf_batch_propagate(s->core, u, dt.data(), VIEKF_HOST);
+  (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
+  if (rc) return rc;
+  return viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST);   // x_[ip], P_[ip] of every filter that stepped
+}
+
+int viekf_seq_add_measurement_t(viekf_seq* s, const double* t, int32_t type, const double* z, int32_t zdim, const double* R,
+                                int32_t rdim, int32_t active, const int32_t* id, const double* depth, const uint8_t* mask,
+                                int32_t* result) {
+  if (!s || !t || !z || !R || !s->indep || zdim < 1 || zdim > 4 || rdim < 1 || rdim > 3) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<int32_t> res(B, VIEKF_MEAS_SKIPPED);
+  std::vector<uint8_t> newf(B, 0);
+  bool any_new = false;
+  for (int b = 0; b < B; b++) {
+    if (mask && !mask[b]) continue;
+    FilterSeq& f = s->fs[b];
+    res[b] = VIEKF_MEAS_SUCCESS;
+    if (t[b] < f.start_t) { res[b] = VIEKF_MEAS_INVALID; continue; }                 // :133-134
+    bool isnan_ = false;
+    for (int k = 0; k < zdim; k++) isnan_ |= std::isnan(z[(size_t)b * zdim + k]);
+    if (isnan_) { res[b] = VIEKF_MEAS_NAN; continue; }                                // :136-137
+    const int gid = id ? id[b] : -1;
+    if (type == VIEKF_FEAT && gid >= 0 && local_id(s, b, gid) < 0) {                  // :140-147
+      res[b] = VIEKF_MEAS_NEW_FEATURE;
+      if ((int)s->ids[b].size() < s->N) { newf[b] = 1; any_new = true; }             // vi_ekf_feat.cpp:9-10
+      continue;
+    }
+    FMeas m;
+    m.t = t[b]; m.type = type; m.zdim = zdim; m.rdim = rdim; m.active = active != 0; m.handled = false; m.id = gid;
+    std::memset(m.z, 0, sizeof m.z);
+    std::memset(m.R, 0, sizeof m.R);
+    std::memcpy(m.z, z + (size_t)b * zdim, sizeof(double) * zdim);
+    std::memcpy(m.R, R, sizeof(double) * rdim * rdim);
+    size_t k = 0;                                                                    // :150-156
+    while (k < f.zbuf.size() && !(f.zbuf[k].t < m.t)) k++;
+    f.zbuf.insert(f.zbuf.begin() + (long)k, m);                                      // :169-175
+  }
+  if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
+    std::vector<double> dep(B, NAN);
+    if (depth) dep.assign(depth, depth + B);
+    std::vector<int32_t> ok(B, 0);
+    if (int rc = viekf_batch_init_feature(s->core, z, dep.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
+    for (int b = 0; b < B; b++)
+      if (newf[b] && ok[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+    if (int rc = refresh_slots(s, newf)) return rc;
+  }
+  if (result) std::memcpy(result, res.data(), sizeof(int32_t) * B);
+  return VIEKF_OK;
+}
+
 int viekf_seq_propagate(viekf_seq* s, const double* u, double t) {
   if (!s || !u) return VIEKF_ERR_INVALID;
+  if (s->indep) { std::vector<double> tt(s->B, t); return viekf_seq_propagate_t(s, u, tt.data(), nullptr); }
   return propagate_core(s, u, t, true);
 }
 
 int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double* z, int32_t zdim, const double* R,
                               int32_t rdim, int32_t active, const int32_t* id, const double* depth, int32_t* result) {
   if (!s || !z || !R || zdim < 1 || zdim > 4 || rdim < 1 || rdim > 3) return VIEKF_ERR_INVALID;
+  if (s->indep) {
+    std::vector<double> tt(s->B, t);
+    return viekf_seq_add_measurement_t(s, tt.data(), type, z, zdim, R, rdim, active, id, depth, nullptr, result);
+  }
   const int B = s->B;
   std::vector<int32_t> res(B, VIEKF_MEAS_SUCCESS);
   SeqMeas m;
@@ -366,6 +706,8 @@ int viekf_seq_init_feature(viekf_seq* s, const double* pix, const double* depth,
   if (int rc = viekf_batch_init_feature(s->core, pix, dep.data(), m.data(), okv.data(), VIEKF_HOST)) return rc;
   for (int b = 0; b < B; b++)
     if (m[b] && okv[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+  if (s->indep)
+    if (int rc = refresh_slots(s, m)) return rc;
   if (ok) std::memcpy(ok, okv.data(), sizeof(int32_t) * B);
   return VIEKF_OK;
 }
@@ -381,6 +723,12 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
         for (int k = 0; k < cap; k++) gated_ids[(size_t)b * cap + k] = k < (int)gated[b].size() ? gated[b][k] : -1;
     return VIEKF_OK;
   };
+  if (s->indep) {   // every filter plans its own rewind / replay; the device steps run batched by kind
+    std::vector<std::vector<SeqOp>> ops(B);
+    for (int b = 0; b < B; b++) plan_handle(s, b, ops[b]);
+    if (int rc = run_ops(s, ops, gated)) return rc;
+    return finish();
+  }
   if (s->zbuf.empty() || s->u.empty()) return finish();            // :12-13
   long zi = (long)s->zbuf.size() - 1;                              // :16-18 oldest unhandled
   while (s->zbuf[zi].handled && zi != 0) zi--;
@@ -514,6 +862,10 @@ int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count
     }
     if (edges) std::memcpy(edges, eb.data(), sizeof(double) * 17 * (size_t)B);
   }
+  if (s->indep && (any_drop || any_reset)) {
+    std::vector<uint8_t> all(B, 1);
+    if (int rc = refresh_slots(s, all)) return rc;
+  }
   if (did_reset) std::memcpy(did_reset, reset.data(), B);
   return VIEKF_OK;
 }
@@ -550,6 +902,7 @@ int viekf_seq_get_global_cov(viekf_seq* s, double* cov) {   // vi_ekf_kfr.cpp:23
 
 int viekf_seq_init_logger(viekf_seq* s, const char* root_filename, const char* ekf_name, int32_t filter) {   // vi_ekf_log.cpp:79-117
   if (!s || !root_filename || !ekf_name || filter < 0 || filter >= s->B) return VIEKF_ERR_INVALID;
+  if (s->indep) return VIEKF_ERR_UNSUPPORTED;   // (the log writer records the lock-step flow: one shared clock)
   const std::string base = std::string(root_filename) + ekf_name;
   s->log.clear();
   s->log.resize(TOTAL_LOGS);
@@ -606,6 +959,14 @@ int viekf_seq_tracked_features(viekf_seq* s, int32_t* ids, int32_t* len) {
 
 int viekf_seq_status(viekf_seq* s, double* t_now, int32_t* ring_index, int32_t* queued, int32_t* inputs) {
   if (!s) return VIEKF_ERR_INVALID;
+  if (s->indep) {   // (independent clocks: the first filter's)
+    const FilterSeq& f = s->fs[0];
+    if (t_now) *t_now = f.t[f.i];
+    if (ring_index) *ring_index = f.i;
+    if (queued) *queued = (int32_t)f.zbuf.size();
+    if (inputs) *inputs = (int32_t)f.u.size();
+    return VIEKF_OK;
+  }
   if (t_now) *t_now = s->t[s->i];
   if (ring_index) *ring_index = s->i;
   if (queued) *queued = (int32_t)s->zbuf.size();

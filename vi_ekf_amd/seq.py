@@ -23,6 +23,9 @@ def _bind():
     L.viekf_seq_status.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.viekf_seq_init_logger.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32]
     L.viekf_seq_disable_logger.argtypes = [vp]
+    L.viekf_seq_create_independent.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.viekf_seq_propagate_t.argtypes = [vp, vp, vp, vp]
+    L.viekf_seq_add_measurement_t.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     L.viekf_seq_get_global_pose.argtypes = [vp, vp, vp]
     L.viekf_seq_get_global_cov.argtypes = [vp, vp]
     L._seq_bound = True
@@ -36,12 +39,16 @@ def _p(a):
 class SeqVIEKF:
     """mirrors vi_ekf::VIEKF's measurement plumbing (reference include/vi_ekf.h:302-308) over a BatchVIEKF"""
 
-    def __init__(self, batch, state_hist=250, meas_hist=200):
+    def __init__(self, batch, state_hist=250, meas_hist=200, independent=False):
+        """independent=True: every filter on its own clock (viekf_seq_create_independent); propagate_state / add_measurement
+        then also take an array of time stamps [B] and an optional mask [B]"""
         self.core = batch
         self.B, self.N = batch.B, batch.N
         self._L = _bind()
+        self.independent = bool(independent)
         h = C.c_void_p()
-        capi.check(self._L.viekf_seq_create(batch._h, int(state_hist), int(meas_hist), C.byref(h)))
+        create = self._L.viekf_seq_create_independent if independent else self._L.viekf_seq_create
+        capi.check(create(batch._h, int(state_hist), int(meas_hist), C.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -52,11 +59,16 @@ class SeqVIEKF:
         except Exception:
             pass
 
-    def propagate_state(self, u, t):
+    def propagate_state(self, u, t, mask=None):
         u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.B, 6)
-        capi.check(self._L.viekf_seq_propagate(self._h, _p(u), float(t)))
+        if np.ndim(t) == 0 and mask is None:
+            capi.check(self._L.viekf_seq_propagate(self._h, _p(u), float(t)))
+            return
+        tt = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        capi.check(self._L.viekf_seq_propagate_t(self._h, _p(u), _p(tt), None if mk is None else _p(mk)))
 
-    def add_measurement(self, t, z, mtype, R, active=False, id=None, depth=None):
+    def add_measurement(self, t, z, mtype, R, active=False, id=None, depth=None, mask=None):
         z = np.ascontiguousarray(z, dtype=np.float64).reshape(self.B, -1)
         R = np.asfortranarray(np.atleast_2d(np.asarray(R, dtype=np.float64)))
         Rf = np.ascontiguousarray(R.ravel(order="F"))
@@ -68,8 +80,14 @@ class SeqVIEKF:
             da = np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float64), (self.B,)))
             dp = _p(da)
         res = np.zeros(self.B, dtype=np.int32)
-        capi.check(self._L.viekf_seq_add_measurement(self._h, float(t), int(mtype), _p(z), z.shape[1], _p(Rf), R.shape[0],
-                                                     int(bool(active)), idp, dp, _p(res)))
+        if np.ndim(t) == 0 and mask is None:
+            capi.check(self._L.viekf_seq_add_measurement(self._h, float(t), int(mtype), _p(z), z.shape[1], _p(Rf), R.shape[0],
+                                                         int(bool(active)), idp, dp, _p(res)))
+            return res
+        tt = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        capi.check(self._L.viekf_seq_add_measurement_t(self._h, _p(tt), int(mtype), _p(z), z.shape[1], _p(Rf), R.shape[0],
+                                                       int(bool(active)), idp, dp, None if mk is None else _p(mk), _p(res)))
         return res
 
     def handle_measurements(self, cap=64):
