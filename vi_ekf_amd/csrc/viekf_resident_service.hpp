@@ -241,6 +241,9 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       d[6] = q.s0; d[7] = q.s1; d[8] = q.s2; d[9] = q.s3; d[10] = q.gate;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifdef VIEKF_TEST_STALL   // test build only (tests/test_gpu_stall.py): filter 0 never publishes its third hand-over -- the body
+    if (S.b == 0 && seq == 3) return;   // wave's bounded wait must give up, raise VIEKF_FLAG_INTERNAL and the launch must end
+#endif
     if (lane == 0) *(lds_vint_t*)(sm + 32 + mb) = seq;
   };
   auto recv = [&](Meas& q, int mb, int seq) {
