@@ -71,7 +71,7 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
                                               (3, 1, 4, 2), (3, 2, 4, 2), (4, 8, 4, 2), (4, 12, 5, 2), (3, 17, 3, 2), (2, 25, 3, 2),
                                               (2, 33, 2, 2), (2, 41, 2, 2), (2, 49, 2, 2), (3, 50, 2, 2),
                                               # N + 14 > 64 lanes: the body lanes on a second service wave (<6,6>, two service waves)
-                                              (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0)])
+                                              (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0), (2, 63, 2, 2), (2, 59, 1, 2)])
 def test_step_parity(B, N, steps, kernel):
     sc = scene.make_scene(B, N, steps, seed=100 + N)
     x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)

@@ -54,7 +54,14 @@ struct viekf_batch {
   size_t res_lds = 0;
   DevParams dp;
   DevParams* d_dp = nullptr;
-  bool upper_stale = false;   // the grouped update left P's upper triangle stale (valid: the lower triangle); see ensure_full_P
+  // P is symmetric and the hot kernels keep only its LOWER triangle current; what is above the diagonal may be stale:
+  //   0  all of P valid
+  //   1  stale outside the diagonal 48 x 48 super-tiles (left by the grouped update; the matrix-core propagate copes)
+  //   2  stale everywhere above the diagonal 3 x 3 blocks (left by the fused kernel, which stores the lower triangle only)
+  // ensure_full_P mirrors the lower triangle up before anything that reads all of P.
+  int upper_stale = 0;
+  int stale_ever = 0;         // the highest level any launch of this batch has left: a ring slot is taken to be that stale when
+                              // it becomes (part of) the live state again -- slots carry no level of their own
   int hist_depth = 0;
   int live_slot = -1;        // >= 0: the live (x, P) ARE this slot of the history ring (d_x / d_P point into it)
   double *home_x = nullptr, *home_P = nullptr;   // the batch's own buffers (live state while live_slot < 0)
@@ -127,13 +134,13 @@ size_t lds_update(const viekf_batch* b) { return sizeof(double) * (size_t)(b->nx
 
 // A grouped update (k_update_feat_blocked) keeps only the lower triangle of P current; the matrix-core propagate reads only
 // that and rewrites all of P.  Everything else reads P whole: mirror the lower triangle up first.
-int ensure_full_P(viekf_batch* b) {
-  if (!b->upper_stale) return VIEKF_OK;
+int ensure_full_P(viekf_batch* b, int tolerate = 0) {
+  if (b->upper_stale <= tolerate) return VIEKF_OK;
   StreamArgs a = make_args(b);
   const int nt = (b->n + 31) / 32;
   hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(nt * (nt + 1) / 2), b->B), dim3(256), 0, b->stream, a);
   HIP_TRY(hipGetLastError());
-  b->upper_stale = false;
+  b->upper_stale = 0;
   return VIEKF_OK;
 }
 
@@ -143,13 +150,12 @@ bool stream_mfma_ok() {   // VIEKF_STREAM_BLOCKED=0 keeps the kernels without ma
 }
 
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
-  if (!stream_mfma_ok())
-    if (int rc = ensure_full_P(b)) return rc;
+  if (int rc = ensure_full_P(b, stream_mfma_ok() ? 1 : 0)) return rc;
   StreamArgs a = make_args(b);
   if (stream_mfma_ok()) {   // feature/feature part on the fp64 matrix cores: reads the lower triangle, writes all of P
     hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2 + 8 * 16 * 17),
                        b->stream, a, d_u, d_dt);
-    b->upper_stale = false;
+    b->upper_stale = 0;
   } else
     hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
                        d_dt);
@@ -197,7 +203,8 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
       have = blds;
     }
     hipLaunchKernelGGL(kern, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb, rsm, d_res);
-    b->upper_stale = true;
+    b->upper_stale = 1;
+    if (b->stale_ever < 1) b->stale_ever = 1;
   } else {
     hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
                        d_slot, M, d_R, rsb, rsm, d_res);
@@ -270,7 +277,7 @@ bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family !
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
                     double* P_out = nullptr, int KP = 1) {
-  if (int rc = ensure_full_P(b)) return rc;
+  // (the fused kernel loads the lower triangle only and stores the lower triangle only: no symmetrisation before or after)
   StreamArgs a = make_args(b);
   if (x_out) { a.x_out = x_out; a.P_out = P_out; }   // (only meaningful for a single-chunk launch)
   long rsb = 0, rsm = 0;
@@ -287,6 +294,8 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
     HIP_TRY(hipGetLastError());
     m0 += mc;
   } while (m0 < M);
+  b->upper_stale = 2;
+  b->stale_ever = 2;
   return VIEKF_OK;
 }
 
@@ -468,7 +477,7 @@ int viekf_batch_reset(viekf_batch* b) {
   StreamArgs a = make_args(b);
   hipLaunchKernelGGL(k_reset, dim3(b->B), dim3(256), 0, b->stream, a, b->d_x0, b->d_Pdiag);
   HIP_TRY(hipGetLastError());
-  b->upper_stale = false;
+  b->upper_stale = 0;
   HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
@@ -552,7 +561,7 @@ int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, cons
     const long tot = (long)b->n * b->n;
     hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((tot + 255) / 256), b->B), dim3(256), 0, b->stream, a);
     HIP_TRY(hipGetLastError());
-    b->upper_stale = false;
+    b->upper_stale = 0;
   }
   if (len_features) HIP_TRY(hipMemcpyAsync(b->d_len, len_features, sizeof(int32_t) * b->B, kind, b->stream));
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
@@ -832,7 +841,9 @@ int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
 
 static int history_copy(viekf_batch* b, int32_t slot, bool save) {
   if (int rc = check_batch(b)) return rc;
-  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
+  // (a covariance is copied as it stands, stale upper triangle included; what comes back from the ring is taken to be as stale
+  //  as anything this batch ever produced)
+  if (!save) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;
   if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
   HIP_TRY(hipSetDevice(b->device));
   const size_t nl = sizeof(int) * (size_t)b->B;
@@ -874,7 +885,7 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, in
   if (b->hist_depth <= 0) return fail(VIEKF_ERR_INVALID, "no history ring (viekf_batch_history_resize first)");
   if (b->live_slot >= 0) return fail(VIEKF_ERR_INVALID, "per-filter ring copies need the live state in the batch's own buffers (viekf_batch_select(-1))");
   HIP_TRY(hipSetDevice(b->device));
-  if (int rc = ensure_full_P(b)) return rc;
+  if (!to_ring) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   if (where == VIEKF_HOST)
     for (int i = 0; i < b->B; i++)
       if (slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
@@ -895,7 +906,7 @@ int viekf_batch_restore_filters(viekf_batch* b, const int32_t* slot, viekf_mem w
 
 int viekf_batch_select(viekf_batch* b, int32_t slot) {
   if (int rc = check_batch(b)) return rc;
-  if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
+  b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   if (slot < -1 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
   if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
   b->live_slot = slot;
@@ -910,7 +921,6 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   if (dst_slot < 0 || dst_slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
   if (dst_slot == b->live_slot) return viekf_batch_propagate(b, u, dt, where);
   HIP_TRY(hipSetDevice(b->device));
-  if (int rc = ensure_full_P(b)) return rc;
   const double *d_u = nullptr, *d_dt = nullptr;
   if (where == VIEKF_HOST)
     if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B) + stage_size(sizeof(double) * b->B))) return rc;

@@ -385,11 +385,10 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   if (flag) atomicOr(&a.flags[S.b], flag);
   RES_STAMP(S, lane == 0, 13);
   {   // cooperative store of P (see res_store_chunk): this wave streams its share of every chunk
-    const StoreChunks sc(N, n, S.img_len);
-    for (int ch = 0; ch < sc.nchunks; ch++) {
-      const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
+    StoreChunk sc;
+    for (int f0 = 0; store_chunk_at(f0, N, n, S.img_len, sc); f0 = sc.f1) {
       __syncthreads();   // S1
-      res_store_chunk<T>(a, S, f0, f1, threadIdx.x);
+      res_store_chunk<T>(a, S, sc, threadIdx.x);
       __syncthreads();   // S2
     }
   }

@@ -6,57 +6,53 @@
 namespace viekf {
 
 
-// Store of P, cooperative part.  The workers scatter their 3x3 blocks (and the mirror images) into an LDS image of a chunk of
-// feature columns -- the Z region, free after the propagate; [column][n rows] -- and the whole workgroup streams the chunk
-// out with lanes along the rows: every wave instruction writes up to 512 contiguous bytes instead of 64 different cache
-// lines (the direct 8-byte block stores were bound by the texture path's one line per clock: 25 k clk per step).
-// Rows 0..15 of a feature column are the mirror of the LDS-resident body columns.
-struct StoreChunks {
-  int fc, nchunks;   // features per chunk, number of chunks
-  __device__ StoreChunks(int N, int n, int img_len) {
-    fc = max(1, min(N, img_len / (3 * n)));
-    nchunks = (N + fc - 1) / fc;
-  }
-};
+// Store of P, cooperative part.  P is symmetric and only its LOWER triangle (and the diagonal 3x3 blocks) is stored: the
+// part above the diagonal is left stale -- the host mirrors it up before anything that reads all of P (ensure_full_P; the
+// fused kernel itself loads the lower triangle only), which halves the HBM bytes of the store phase.  The workers scatter
+// their 3x3 blocks, each in its lower-triangle orientation, into an LDS image of a chunk of feature columns -- the Z region
+// and its neighbours, free after the update loop; [column][rows rb .. n) -- and the whole workgroup streams the chunk out with
+// lanes along the rows: every wave instruction writes up to 1 KB contiguous instead of 64 different cache lines (the direct
+// 8-byte block stores were bound by the texture path's one line per clock: 25 k clk per step).  A chunk's image starts at
+// its first column's diagonal, so later chunks hold more columns (N = 50: 13 + 17 + 20 features).
+struct StoreChunk { int f0, f1, rb, h; };   // features [f0, f1), image rows rb .. rb + h - 1 (rb, h even)
+__device__ __forceinline__ bool store_chunk_at(int f0, int N, int n, int img_len, StoreChunk& c) {
+  if (f0 >= N) return false;
+  c.f0 = f0;
+  c.rb = (16 + 3 * f0) & ~1;
+  c.h = ((n + 1) & ~1) - c.rb;
+  c.f1 = min(N, f0 + max(1, img_len / (3 * c.h)));
+  return true;
+}
 template <int T>
-__device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResShared& S, int f0, int f1, int tid) {
+__device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResShared& S, const StoreChunk& c, int tid) {
   const int n = S.n, ld = a.ld;
   double* P = a.P_out + (long)S.b * n * ld;
   const double* img = S.Z;
-  const int ncol = 3 * (f1 - f0), lane = tid & 63, w = tid >> 6;
+  const int ncol = 3 * (c.f1 - c.f0), lane = tid & 63, w = tid >> 6;
   constexpr int NWV = T / 64;
-  if ((n & 1) == 0) {   // even n: row pairs are 16-byte aligned in the image, in Pbc and in P (ld is even)
-#pragma unroll 4
-    for (int c = w; c < ncol; c += NWV) {
-      const int j = 16 + 3 * f0 + c;
-      double2 v[2];
+  if ((n & 1) == 0) {   // even n: row pairs are 16-byte aligned in the image and in P (ld is even)
+#pragma unroll 2
+    for (int col = w; col < ncol; col += NWV) {
+      const int j = 16 + 3 * c.f0 + col;
+      const double* src = img + col * c.h - c.rb;
+      for (int i0 = c.rb; i0 < n; i0 += 256) {
+        double2 v[2];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int i = 2 * (lane + 64 * u);
-        const double* src = (i < 16) ? (S.Pbc + (j - 16) * 16 + i) : (img + c * n + min(i, n - 2));
-        v[u] = lds_ld2(src);
-      }
+        for (int u = 0; u < 2; u++) v[u] = lds_ld2(src + min(i0 + 2 * (lane + 64 * u), n - 2));
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int i = 2 * (lane + 64 * u);
-        if (i < n) *reinterpret_cast<double2*>(P + i + (long)j * ld) = v[u];
+        for (int u = 0; u < 2; u++) {
+          const int i = i0 + 2 * (lane + 64 * u);
+          if (i < n && i + 1 >= j) *reinterpret_cast<double2*>(P + i + (long)j * ld) = v[u];   // rows on and below the diagonal
+        }
       }
     }
   } else {
 #pragma unroll 2
-    for (int c = w; c < ncol; c += NWV) {
-      const int j = 16 + 3 * f0 + c;
-      double v[3];
-#pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int i = lane + 64 * u;
-        v[u] = (i < 16) ? S.Pbc[(j - 16) * 16 + i] : img[c * n + min(i, n - 1)];
-      }
-#pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int i = lane + 64 * u;
-        if (i < n) P[i + (long)j * ld] = v[u];
-      }
+    for (int col = w; col < ncol; col += NWV) {
+      const int j = 16 + 3 * c.f0 + col;
+      const double* src = img + col * c.h - c.rb;
+      for (int i = c.rb + lane; i < n; i += 64)
+        if (i >= j) P[i + (long)j * ld] = src[i];
     }
   }
 }
@@ -139,11 +135,18 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     for (int ia = 0; ia < RB; ia++) {
       int I, J;
       blk(tq, ia, I, J);
-      const double* pu = P + ((16 + 3 * I) + (long)(16 + 3 * J) * ld);
+      // only the lower triangle of P is valid in memory (see the store): a block above the diagonal is read as the transpose
+      // of its mirror, a diagonal block takes its lower triangle for both
+      const bool up = I < J;
+      const int br = 16 + 3 * (up ? J : I), bc = 16 + 3 * (up ? I : J);
+      const double* pu = P + (br + (long)bc * ld);
 #pragma unroll
       for (int s = 0; s < 3; s++)
 #pragma unroll
-        for (int r = 0; r < 3; r++) pb[ia][r * 3 + s] = pu[r + (long)s * ld];
+        for (int r = 0; r < 3; r++) {
+          const int rr = (I == J) ? max(r, s) : (up ? s : r), cc = (I == J) ? min(r, s) : (up ? r : s);
+          pb[ia][r * 3 + s] = pu[rr + (long)cc * ld];
+        }
     }
     // body columns -> LDS (coalesced along rows)
     for (int e = tid; e < nf * 16; e += TW) {
@@ -151,10 +154,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
     }
     // (the body block is kept EXACTLY symmetric, like every other part of P here -- see sym_diag below: both copies of a pair
-    //  are loaded from the upper triangle)
+    //  are loaded from the lower triangle)
     for (int e = tid; e < 256; e += TW) {
       const int r = e & 15, c = e >> 4;
-      Pbb[r * 16 + c] = P[min(r, c) + (long)max(r, c) * ld];
+      Pbb[r * 16 + c] = P[max(r, c) + (long)min(r, c) * ld];
     }
   }
 
@@ -482,37 +485,39 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];
     }
     for (int e = opaque(tid); e < 256; e += TW) P[(e >> 4) + (long)(e & 15) * ld] = Pbb[e];
-    const StoreChunks sc(N, n, S.img_len);
     double* img = S.Z;
     const int gtid = threadIdx.x;
     RES_STAMP(S, tid == 0, 224);
-    for (int ch = 0; ch < sc.nchunks; ch++) {
-      const int f0 = ch * sc.fc, f1 = min(N, f0 + sc.fc);
+    StoreChunk sc;
+    int ch = 0;
+    for (int f0 = 0; store_chunk_at(f0, N, n, S.img_len, sc); f0 = sc.f1, ch++) {
+      const int f1 = sc.f1;
       const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
         int I, J;
         if (blk(tq, ia, I, J)) {
-          if (J >= f0 && J < f1) {                          // block (I,J): columns of feature J
-            double* d = img + (3 * (J - f0)) * n + 16 + 3 * I;
+          // the block in its lower-triangle orientation: (I, J) itself for I >= J, its mirror (J, I) otherwise
+          if (I >= J && J >= f0 && J < f1) {                // rows of feature I in the columns of feature J
+            double* d = img + (3 * (J - f0)) * sc.h + (16 + 3 * I - sc.rb);
 #pragma unroll
             for (int s = 0; s < 3; s++)
 #pragma unroll
-              for (int r = 0; r < 3; r++) d[s * n + r] = pb[ia][r * 3 + s];
+              for (int r = 0; r < 3; r++) d[s * sc.h + r] = pb[ia][r * 3 + s];
           }
-          if (I != J && I >= f0 && I < f1) {                // its mirror (J,I): columns of feature I
-            double* d = img + (3 * (I - f0)) * n + 16 + 3 * J;
+          if (I < J && I >= f0 && I < f1) {                 // rows of feature J in the columns of feature I
+            double* d = img + (3 * (I - f0)) * sc.h + (16 + 3 * J - sc.rb);
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-              for (int s = 0; s < 3; s++) d[r * n + s] = pb[ia][r * 3 + s];
+              for (int s = 0; s < 3; s++) d[r * sc.h + s] = pb[ia][r * 3 + s];
           }
         }
       }
       RES_STAMP(S, tid == 0 && ch < 3, 225 + 4 * ch);
       __syncthreads();   // S1: the chunk image is complete
       RES_STAMP(S, tid == 0 && ch < 3, 226 + 4 * ch);
-      res_store_chunk<T>(a, S, f0, f1, gtid);
+      res_store_chunk<T>(a, S, sc, gtid);
       RES_STAMP(S, tid == 0 && ch < 3, 227 + 4 * ch);
       __syncthreads();   // S2: the image may be overwritten
       RES_STAMP(S, tid == 0 && ch < 3, 228 + 4 * ch);
