@@ -345,7 +345,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("k_step_resident (one fused launch per step: propagate + %d updates, P resident in "
-                                    "VGPRs/LDS), median HIP-event duration %.4f ms" % (N, launch_s * 1e3)) if (N <= 50 and args.kernel != 1)
+                                    "VGPRs/LDS; instance %s), median HIP-event duration %.4f ms"
+                                    % (N, "<3,2> two workgroups per CU" if (N <= 25 and B > 256) else
+                                       ("<7,3> two 256-thread workgroups per CU" if (26 <= N <= 50 and B > 256) else
+                                        ("<6,6> two service waves" if N > 50 else "<3,7>")), launch_s * 1e3)) if (N <= 64 and args.kernel != 1)
                                    else ("k_propagate_stream + k_update_feat_blocked (P in HBM, one pass per 16 updates, fp64 MFMA passes in both kernels), "
                                          "median HIP-event duration of the step's launches %.4f ms" % (launch_s * 1e3)),
                          "alg_bytes_per_launch": alg_bytes},
