@@ -222,6 +222,7 @@ const ResInst kResInst[] = {
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
+    {4, 5, 26, 50, 80, 1},   // two 384-thread workgroups per CU: three waves per SIMD (<= 168 VGPRs)
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
 
@@ -233,6 +234,7 @@ res_kernel_t res_kernel(int inst, bool multi = false) {   // multi: several prop
     case 1: return multi ? k_step_resident<7, 3, true> : k_step_resident<7, 3, false>;
     case 2: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
     case 3: return multi ? k_step_resident<6, 6, true, 2> : k_step_resident<6, 6, false, 2>;
+    case 4: return multi ? k_step_resident<4, 5, true> : k_step_resident<4, 5, false>;
   }
   return nullptr;
 }
@@ -249,7 +251,7 @@ int setup_resident(viekf_batch* b) {
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > (size_t)r.max_lds_kb * 1024) continue;
-    if (r.NW <= 3 && !force) {   // two small workgroups per CU only pay when the batch fills the CUs more than once
+    if (r.max_lds_kb <= 80 && !force) {   // two small workgroups per CU only pay when the batch fills the CUs more than once
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
       if (b->B <= cus) continue;

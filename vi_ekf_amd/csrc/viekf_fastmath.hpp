@@ -15,6 +15,15 @@ __device__ __forceinline__ double rcp_fast(double d) {
   return fma(r, e, r);
 }
 
+// A double literal that is not an inline constant, materialised in SGPRs at the point of use.  Inside the per-update loops the
+// compiler otherwise hoists every such literal into a VGPR pair for the whole loop (the 18 series coefficients below alone
+// were 36 VGPRs of the service wave's live set -- spilled to scratch and re-loaded every update under a tighter register cap).
+__device__ __forceinline__ double kconst(double v) {
+  unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // exp() of a small rotation vector as a quaternion (src/quat.cpp:64-80).  For |v| < 0.5 both
 // cos(h) and sin(h)/(2h), h = |v|/2, are even series in h^2 -- no sqrt, no range reduction; they
 // agree with either branch of the reference (the 1e-4 small-angle branch differs from the exact
@@ -23,35 +32,35 @@ __device__ __forceinline__ void q_exp_fast(const double* v, double* o) {
   const double n2 = dot3(v, v);
   const double h2 = 0.25 * n2;
   if (h2 < 2.5e-3) {                              // |v| < 0.1: truncation < 3e-20, the usual size of a filter correction
-    double c = 1.0 / 40320.0;
-    c = fma(c, h2, -1.0 / 720.0);
-    c = fma(c, h2, 1.0 / 24.0);
+    double c = kconst(1.0 / 40320.0);
+    c = fma(c, h2, kconst(-1.0 / 720.0));
+    c = fma(c, h2, kconst(1.0 / 24.0));
     c = fma(c, h2, -0.5);
     c = fma(c, h2, 1.0);                          // cos(h)
-    double s = 1.0 / 362880.0;
-    s = fma(s, h2, -1.0 / 5040.0);
-    s = fma(s, h2, 1.0 / 120.0);
-    s = fma(s, h2, -1.0 / 6.0);
+    double s = kconst(1.0 / 362880.0);
+    s = fma(s, h2, kconst(-1.0 / 5040.0));
+    s = fma(s, h2, kconst(1.0 / 120.0));
+    s = fma(s, h2, kconst(-1.0 / 6.0));
     s = fma(s, h2, 1.0);                          // sin(h)/h
     s *= 0.5;
     o[0] = c; o[1] = s * v[0]; o[2] = s * v[1]; o[3] = s * v[2];
   } else if (h2 < 0.0625) {
-    double c = -1.0 / 20922789888000.0;          // -1/16!
-    c = fma(c, h2, 1.0 / 87178291200.0);          // 1/14!
-    c = fma(c, h2, -1.0 / 479001600.0);           // -1/12!
-    c = fma(c, h2, 1.0 / 3628800.0);              // 1/10!
-    c = fma(c, h2, -1.0 / 40320.0);               // -1/8!
-    c = fma(c, h2, 1.0 / 720.0);
-    c = fma(c, h2, -1.0 / 24.0);
+    double c = kconst(-1.0 / 20922789888000.0);          // -1/16!
+    c = fma(c, h2, kconst(1.0 / 87178291200.0));          // 1/14!
+    c = fma(c, h2, kconst(-1.0 / 479001600.0));           // -1/12!
+    c = fma(c, h2, kconst(1.0 / 3628800.0));              // 1/10!
+    c = fma(c, h2, kconst(-1.0 / 40320.0));               // -1/8!
+    c = fma(c, h2, kconst(1.0 / 720.0));
+    c = fma(c, h2, kconst(-1.0 / 24.0));
     c = fma(c, h2, 0.5);
     c = fma(-c, h2, 1.0);                         // cos(h)
-    double s = -1.0 / 1307674368000.0;            // -1/15!
-    s = fma(s, h2, 1.0 / 6227020800.0);           // 1/13!
-    s = fma(s, h2, -1.0 / 39916800.0);            // -1/11!
-    s = fma(s, h2, 1.0 / 362880.0);               // 1/9!
-    s = fma(s, h2, -1.0 / 5040.0);
-    s = fma(s, h2, 1.0 / 120.0);
-    s = fma(s, h2, -1.0 / 6.0);
+    double s = kconst(-1.0 / 1307674368000.0);            // -1/15!
+    s = fma(s, h2, kconst(1.0 / 6227020800.0));           // 1/13!
+    s = fma(s, h2, kconst(-1.0 / 39916800.0));            // -1/11!
+    s = fma(s, h2, kconst(1.0 / 362880.0));               // 1/9!
+    s = fma(s, h2, kconst(-1.0 / 5040.0));
+    s = fma(s, h2, kconst(1.0 / 120.0));
+    s = fma(s, h2, kconst(-1.0 / 6.0));
     s = fma(s, h2, 1.0);                          // sin(h)/h
     s *= 0.5;
     o[0] = c; o[1] = s * v[0]; o[2] = s * v[1]; o[3] = s * v[2];

@@ -79,7 +79,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
 }
 
 template <int RB, int NW, bool MP = false, int NS = 1>
-__global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
+__global__ __launch_bounds__((NW + NS) * 64, (RB == 4 && NW == 5) ? 3 : ((NW <= 3) ? 2 : 1)) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
                                                                 const double* __restrict__ z_all,

@@ -116,12 +116,12 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   const bool rowlane = isfeat || (jb >= 0 && jb < 14);   // this lane owns rows of K / W (the others only tag along)
   double* qptr = isfeat ? (xs + xZ + 5 * lane) : (xs + xATT);
   double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0))));
-  const double rho_reset = 1.0 / (2.0 * prm.min_depth);
-  const double lam0 = partial ? S.lam[rid0] : 1.0, lam1 = partial ? S.lam[rid1] : 1.0, lam2 = partial ? S.lam[rid2] : 1.0;
+  // (wave-uniform constants of the update loop are forced into SGPRs: as VGPR pairs they were a fifth of the loop's live set)
+  const double rho_reset = uniform_f64(1.0 / (2.0 * prm.min_depth));
   // Lambda of the zeta-zeta 2x2 block (lambda_feat[0], lambda_feat[1])
-  const double lz0 = a.lambda[16], lz1 = a.lambda[17];
-  const double L00 = partial ? (lz0 + lz0 - lz0 * lz0) : 1.0, L01 = partial ? (lz0 + lz1 - lz0 * lz1) : 1.0,
-               L11 = partial ? (lz1 + lz1 - lz1 * lz1) : 1.0;
+  const double lz0 = uniform_f64(a.lambda[16]), lz1 = uniform_f64(a.lambda[17]);
+  const double L00 = uniform_f64(partial ? (lz0 + lz0 - lz0 * lz0) : 1.0), L01 = uniform_f64(partial ? (lz0 + lz1 - lz0 * lz1) : 1.0),
+               L11 = uniform_f64(partial ? (lz1 + lz1 - lz1 * lz1) : 1.0);
 
   // Each feature lane keeps its own P_zeta,zeta (2x2) current through the updates, so the lane of the NEXT measurement can
   // form  S = Hb P_zz Hb^T + R,  S^-1  and the gate verdict right after its prediction -- at the END of an iteration.
@@ -206,7 +206,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // k3), with the workers' expression  p - Lambda (K . W):  feature rows i take K_i (own) and W of the column's feature,
   // body rows k take K of the column's feature and W_k, as the block sweep and the body-column sweep do.  Everything this
   // needs is complete at the top of a phase, so it runs there, off the critical path.
-  const double lfz[3] = {a.lambda[16], a.lambda[17], a.lambda[18]};
+  const double lfz[3] = {lz0, lz1, uniform_f64(a.lambda[18])};
   auto next_rows = [&](int rb, bool swept, int slot, const double* Kc, const double2 (&k3)[3], double2 (&o)[3]) {
     const double* raw = S.Praw + rb * 2 * n;
     const double* Wc = Kc + 2 * n;
@@ -289,6 +289,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
+    const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
     const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
     const double dv1 = (lam1 * kB.x) * r0 + (lam1 * kB.y) * r1;
     const double dv2 = (lam2 * kC.x) * r0 + (lam2 * kC.y) * r1;

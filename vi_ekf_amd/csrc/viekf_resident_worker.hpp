@@ -397,7 +397,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const int it = tid;
     // ---- (1) feature/feature blocks (registers).  The operand rows of GB blocks are in flight together: all of them with
     //      few blocks per thread; two at a time with many, where holding every block's rows would not fit the register file
-    constexpr int GB = (RB <= 4) ? RB : 2;
+    constexpr int GB = (RB <= 3) ? RB : 2;
     const bool gated = gflag != 0.0;
     const bool run = !gated && nanw == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     bool fixed = false;
