@@ -86,6 +86,23 @@ def test_step_parity(B, N, steps, kernel):
     assert (g.get_status() & 1 == 0).all()
 
 
+@pytest.mark.parametrize("N,kernel", [(12, 2), (50, 2), (57, 2), (30, 1), (70, 0)])
+def test_general_lambda_on_the_bearing_components(N, kernel):
+    """lambda_feat with entries != 1 on the bearing components: the fused kernel's general-Lambda instances (the reference's
+    parameter files keep those at 1, which the ZU instances exploit; vi_ekf_meas.cpp:250-257)"""
+    B, steps = 3, 3
+    over = dict(lam_feat=[0.7, 0.85, 0.4], lam=[1.0] * 3 + [0.9] * 3 + [0.8] * 3 + [0.1] * 6 + [0.01])
+    sc = scene.make_scene(B, N, steps, seed=900 + N, params=over)
+    x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)
+    g = make_gpu(sc, B, N, kernel=kernel)
+    res = np.zeros_like(res_ref)
+    for s in range(steps):
+        res[s] = g.step(sc["u"][s], sc["dt"], sc["z"][s], sc["slot"], sc["R"])
+    assert (res == res_ref).all()
+    assert_close(g.get_state(), x_ref, "x")
+    assert_close(g.get_covariance(), P_ref, "P")
+
+
 def test_init_state_matches_oracle():
     sc = scene.make_scene(2, 5, 1, seed=7)
     g = make_gpu(sc, 2, 5, nfeat=3)

@@ -46,8 +46,8 @@ for it in range(8):
 it = 3
 for w in range(7):
     q = 192 + 4 * w
-    print("update 3 worker wave %d: phase top -> before B1 %5d | B1 wait %5d   (top skew vs wave 0: %d)" % (
-        w, d(q, q + 1), d(q + 1, q + 3), int(t[q] - t[192])))
+    print("update 3 worker wave %d: blocks+publish %5d | body columns %5d | B1 wait %5d   (top skew vs wave 0: %d)" % (
+        w, d(q, q + 2), d(q + 2, q + 1), d(q + 1, q + 3), int(t[q] - t[192])))
 print("service tail: ", d(11, 12), d(12, 13), " worker store", d(72, 73), " total service", d(0, 13), " total worker", d(62, 73))
 print("store: body cols %d" % d(72, 224))
 for ch in range(3):

@@ -3,6 +3,7 @@
 // host-pointer arguments, launches the gfx950 kernels.  No CPU fallback exists on purpose.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,7 @@ struct viekf_batch {
   size_t stage_bytes = 0, stage_used = 0;
   int family = 0;       // requested: 0 auto, 1 streaming, 2 resident
   int res_inst = -1;    // resident instance index (-1: N not covered by the resident family)
+  bool res_zu = false;  // lambda = 1 on the bearing components (or no partial update): the fused kernel's ZU instances apply
   int res_TR = 0, res_TC = 0;
   size_t res_lds = 0;
   DevParams dp;
@@ -69,6 +71,7 @@ struct viekf_batch {
   int* h_len = nullptr;
   unsigned char* d_active = nullptr;   // [B] participation mask of the next propagate / feature-update launches (NULL: all)
   bool active_on = false;
+  int* d_resmap = nullptr;             // fused-step kernel: block ownership map [RB][TW] of the chosen instance (build_resmap)
   int* d_ringslot = nullptr;           // [B] staging of per-filter ring slots (viekf_batch_snapshot_filters / _restore_filters)
 };
 
@@ -83,6 +86,7 @@ StreamArgs make_args(const viekf_batch* b) {
   a.dp = b->d_dp;
   a.x_out = b->d_x; a.P_out = b->d_P;
   a.active = b->active_on ? b->d_active : nullptr;
+  a.resmap = b->d_resmap;
   return a;
 }
 
@@ -222,19 +226,126 @@ const ResInst kResInst[] = {
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
-    {4, 5, 26, 50, 80, 1},   // two 384-thread workgroups per CU: three waves per SIMD (<= 168 VGPRs)
+    // (<4, 5> -- two 384-thread workgroups per CU, three waves per SIMD at <= 168 VGPRs -- measured 32 % slower: dropped)
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
 
+// Ownership map of the fused-step kernel: which 3x3 feature block P[16+3I.., 16+3J..] (I >= J: one of each symmetric pair)
+// lives in slot `a` of worker thread t.  Entry [a][t] = I | J << 8 | owned << 16.
+//  * slot 0 of the threads t < N holds the diagonal blocks (t, t) (the kernel's own_diag convention);
+//  * every other (slot, wave) pair is a GROUP of 64 lanes.  The strictly lower blocks are cut into 8 x 8 tiles of features;
+//    a full tile fills one group with lane = 8 i + j  <->  block (8 TI + i, 8 TJ + j).  Every update publishes the column
+//    pair of ONE feature s from the registers that hold it: the blocks {., s} then sit in the few groups whose tile row or
+//    tile column contains s -- at N = 50 on three worker waves 2.6 groups per wave on average (at most 4) instead of 6.7
+//    (at most 7) with the blocks dealt round-robin along wrapped diagonals (r01/r02a), and each group costs its wave the
+//    whole extraction body whether one lane matches or eight.  The LDS reads of a tile's operand rows (K rows by i, W rows by
+//    j: 48 bytes apart) are conflict-free in every 16-lane service group of ds_read_b128.
+//  * what is left (the triangles of the diagonal tiles, the ragged last tile row when N is not a multiple of 8) is packed
+//    unit by unit into the remaining lanes, best fit first.
+// Returns false when the blocks do not fit RB slots of TW threads.
+bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
+  const int TW = 64 * NWV;
+  map.assign((size_t)RB * TW, 0);
+  if (N > TW || N > 255) return false;
+  auto put = [&](int slot, int t, int I, int J) { map[(size_t)slot * TW + t] = I | (J << 8) | (1 << 16); };
+  for (int t = 0; t < N; t++) put(0, t, t, t);
+  struct Group { int slot, wave; std::vector<int> free_lanes; };
+  std::vector<Group> groups;
+  for (int s = 0; s < RB; s++)
+    for (int w = 0; w < NWV; w++) {
+      Group g{s, w, {}};
+      for (int l = 0; l < 64; l++)
+        if (!(s == 0 && 64 * w + l < N)) g.free_lanes.push_back(l);
+      groups.push_back(g);
+    }
+  typedef std::vector<std::pair<int, int>> Unit;
+  std::vector<Unit> ragged;
+  const int kf = N / 8, r = N % 8;
+  for (int TI = 0; TI < kf; TI++)
+    for (int TJ = 0; TJ < TI; TJ++) {
+      // a full group, preferably on wave (TI + TJ) mod NWV: the tiles of one tile row / column then spread over the waves
+      const int pref = (TI + TJ) % NWV;
+      int best = -1, bestkey = 1 << 30;
+      for (int g = 0; g < (int)groups.size(); g++) {
+        if (groups[g].free_lanes.size() != 64) continue;
+        const int key = ((groups[g].wave - pref + NWV) % NWV) * 64 + groups[g].slot;
+        if (key < bestkey) { bestkey = key; best = g; }
+      }
+      if (best < 0) {
+        Unit u;
+        for (int i = 0; i < 8; i++)
+          for (int j = 0; j < 8; j++) u.push_back({8 * TI + i, 8 * TJ + j});
+        ragged.push_back(u);
+        continue;
+      }
+      for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) put(groups[best].slot, 64 * groups[best].wave + 8 * i + j, 8 * TI + i, 8 * TJ + j);
+      groups[best].free_lanes.clear();
+    }
+  for (int TD = 0; TD < kf; TD++) {
+    Unit u;
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < i; j++) u.push_back({8 * TD + i, 8 * TD + j});
+    ragged.push_back(u);
+  }
+  if (r) {
+    for (int TJ = 0; TJ < kf; TJ++) {
+      Unit u;
+      for (int i = 0; i < r; i++)
+        for (int j = 0; j < 8; j++) u.push_back({8 * kf + i, 8 * TJ + j});
+      ragged.push_back(u);
+    }
+    Unit u;
+    for (int i = 0; i < r; i++)
+      for (int j = 0; j < i; j++) u.push_back({8 * kf + i, 8 * kf + j});
+    if (!u.empty()) ragged.push_back(u);
+  }
+  std::stable_sort(ragged.begin(), ragged.end(), [](const Unit& x, const Unit& y) { return x.size() > y.size(); });
+  for (const Unit& u : ragged) {
+    int best = -1;
+    size_t bestslack = ~(size_t)0;
+    for (int g = 0; g < (int)groups.size(); g++) {
+      const size_t f = groups[g].free_lanes.size();
+      if (f >= u.size() && f - u.size() < bestslack) { bestslack = f - u.size(); best = g; }
+    }
+    size_t k = 0;
+    if (best >= 0) {
+      Group& G = groups[best];
+      for (; k < u.size(); k++) { put(G.slot, 64 * G.wave + G.free_lanes.front(), u[k].first, u[k].second); G.free_lanes.erase(G.free_lanes.begin()); }
+      continue;
+    }
+    // no group takes the unit whole: split it over the emptiest ones
+    while (k < u.size()) {
+      int big = -1;
+      for (int g = 0; g < (int)groups.size(); g++)
+        if (!groups[g].free_lanes.empty() && (big < 0 || groups[g].free_lanes.size() > groups[big].free_lanes.size())) big = g;
+      if (big < 0) return false;
+      Group& G = groups[big];
+      while (k < u.size() && !G.free_lanes.empty()) {
+        put(G.slot, 64 * G.wave + G.free_lanes.front(), u[k].first, u[k].second);
+        G.free_lanes.erase(G.free_lanes.begin());
+        k++;
+      }
+    }
+  }
+  return true;
+}
+
 typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
                              const double*, long, long, int*);
-res_kernel_t res_kernel(int inst, bool multi = false) {   // multi: several propagates per launch (viekf_batch_step_n)
+// multi: several propagates per launch (viekf_batch_step_n); zu: the unit-Lambda instances (both flavours: step_n must stay
+// bit for bit what K propagates and a step give)
+template <int RB, int NW, int NS>
+res_kernel_t res_pick(bool multi, bool zu) {
+  if (multi) return zu ? k_step_resident<RB, NW, true, NS, true> : k_step_resident<RB, NW, true, NS, false>;
+  return zu ? k_step_resident<RB, NW, false, NS, true> : k_step_resident<RB, NW, false, NS, false>;
+}
+res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
   switch (inst) {
-    case 0: return multi ? k_step_resident<3, 2, true> : k_step_resident<3, 2, false>;
-    case 1: return multi ? k_step_resident<7, 3, true> : k_step_resident<7, 3, false>;
-    case 2: return multi ? k_step_resident<3, 7, true> : k_step_resident<3, 7, false>;
-    case 3: return multi ? k_step_resident<6, 6, true, 2> : k_step_resident<6, 6, false, 2>;
-    case 4: return multi ? k_step_resident<4, 5, true> : k_step_resident<4, 5, false>;
+    case 0: return res_pick<3, 2, 1>(multi, zu);
+    case 1: return res_pick<7, 3, 1>(multi, zu);
+    case 2: return res_pick<3, 7, 1>(multi, zu);
+    case 3: return res_pick<6, 6, 2>(multi, zu);
   }
   return nullptr;
 }
@@ -256,9 +367,18 @@ int setup_resident(viekf_batch* b) {
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
       if (b->B <= cus) continue;
     }
+    std::vector<int> map;
+    if (!build_resmap(b->N, r.RB, r.NW, map)) continue;
+    if (b->d_resmap) { HIP_TRY(hipFree(b->d_resmap)); b->d_resmap = nullptr; }
+    HIP_TRY(hipMalloc(&b->d_resmap, sizeof(int) * map.size()));
+    HIP_TRY(hipMemcpy(b->d_resmap, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, false, true)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true, true)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
     break;
@@ -289,7 +409,7 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   int m0 = 0;
   do {
     const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
-    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1), dim3(b->B), dim3((r.NW + r.NS) * 64), b->res_lds, b->stream, a, b->res_TR,
+    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1, b->res_zu), dim3(b->B), dim3((r.NW + r.NS) * 64), b->res_lds, b->stream, a, b->res_TR,
                        b->res_TC, ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
@@ -451,6 +571,8 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   up(b->d_Pdiag, Pd.data(), b->n);
   up(b->d_x0, p->x0, 17);
   if (hipMemcpy(b->d_dp, &b->dp, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess) rc = VIEKF_ERR_HIP;
+  b->res_zu = !p->use_partial_update || (p->lambda_feat[0] == 1.0 && p->lambda_feat[1] == 1.0);
+  if (getenv("VIEKF_RES_NOZU")) b->res_zu = false;   // (experiments / tests: the general-Lambda instances)
   if (rc == VIEKF_OK) rc = setup_resident(b);
   if (rc == VIEKF_OK) rc = viekf_batch_reset(b);
   if (rc != VIEKF_OK) {
@@ -465,7 +587,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_active, b->d_ringslot};
+  void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_active, b->d_ringslot, b->d_resmap};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);

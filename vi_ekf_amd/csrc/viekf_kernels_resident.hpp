@@ -78,8 +78,10 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   RES_STAMP(S, tid == 0, 63);
 }
 
-template <int RB, int NW, bool MP = false, int NS = 1>
-__global__ __launch_bounds__((NW + NS) * 64, (RB == 4 && NW == 5) ? 3 : ((NW <= 3) ? 2 : 1)) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
+// ZU: lambda = 1 on the bearing components of every feature (the reference's parameter files: lambda_feat = [1, 1, x]; checked
+// by the host), which makes Lambda = 1 for every element of a feature/feature block except (rho, rho).
+template <int RB, int NW, bool MP = false, int NS = 1, bool ZU = false>
+__global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
                                                                 const double* __restrict__ z_all,
@@ -101,10 +103,10 @@ __global__ __launch_bounds__((NW + NS) * 64, (RB == 4 && NW == 5) ? 3 : ((NW <= 
   if (NS == 2) {
     if (wave == NW) res_service<T, MP, 1>(a, S, tid & 63, NW, u_all, dt_all, result_all);
     else if (wave == NW + 1) res_service<T, MP, 2>(a, S, tid & 63, NW, u_all, dt_all, result_all);
-    else res_worker<RB, TW, MP, T>(a, S, tid);
+    else res_worker<RB, TW, MP, T, ZU>(a, S, tid);
   } else {
     if (wave == SVC) res_service<T, MP>(a, S, tid & 63, NW, u_all, dt_all, result_all);
-    else res_worker<RB, TW, MP, T>(a, S, tid - (wave > SVC ? 64 : 0));
+    else res_worker<RB, TW, MP, T, ZU>(a, S, tid - (wave > SVC ? 64 : 0));
   }
 }
 

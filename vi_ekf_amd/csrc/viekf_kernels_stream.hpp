@@ -30,6 +30,7 @@ struct StreamArgs {
   double* P_out;        // slot of the history ring (viekf_batch_propagate_to: the propagate writes the NEXT slot, no copy)
   const unsigned char* active;   // [B] or NULL: filters with active[b] == 0 take no part in a propagate / feature-update launch
                                  // (viekf_batch_set_active: filters on different clocks share a batch)
+  const int* resmap;    // fused-step kernel: ownership map of the 3x3 feature blocks, [RB][TW] entries I | J << 8 | owned << 16
 };
 
 constexpr int WK = 40;   // contraction depth of the low-rank part (16 + 16 + 6, padded to whole MFMA k-steps of 4)

@@ -92,41 +92,35 @@ __device__ __forceinline__ void res_body_items(const ResShared& S, const double*
     }
   }
 }
-// how many of the 8 N body-column items of an update the service wave sweeps (after its chain), by worker-wave count
+// how many of the 8 N body-column items of an update the service wave sweeps (after its chain), by worker-wave count.
+// With the blocks dealt round-robin along wrapped diagonals (r02a) the three worker waves of <7,3> were the longer side and 5 N
+// items on the service wave paid 9 %; with the tile map (build_resmap) the service chain is the longest wave of an update again
+// and every share > 0 measured slower (N = 50, B = 1024: 0 / N / 2 N items -> 0.348 / 0.347 / 0.353 ms per step).
 template <int NWV>
-// (measured at N = 50, two workgroups per CU: 0 / 64 / 128 / 192 / 256 / 320 / 400 of the 400 items -> 0.456 / 0.428 / 0.431 /
-//  0.424 / 0.415 / 0.431 / 0.457 ms per step)
-__device__ __forceinline__ int res_service_items(int N) { return (NWV == 3) ? ((5 * N + 7) & ~7) : 0; }
+__device__ __forceinline__ int res_service_items(int N) { return 0; }
 
-template <int RB, int TW, bool MP, int T = TW + 64>
+template <int RB, int TW, bool MP, int T = TW + 64, bool ZU = false>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
   double* P = a.P + (long)S.b * n * ld;
-  // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept, on wrapped diagonals
-  //   J = (I + d) mod N,  d = 0 .. N/2   (for even N the diagonal d = N/2 would hold every pair twice: only its rows
-  //   I < N/2 are owned).  The N (N + 1) / 2 owned blocks are numbered  idx = d N + I  and dealt round-robin: thread t keeps
-  //   idx = t + TW a, a < RB  -- any thread count, RB = ceil(N (N + 1) / 2 / TW) blocks per thread, and the lanes of a wave
-  //   hold consecutive rows I of (mostly) one diagonal.  Slot a = 0 of the threads t < N is the diagonal d = 0.
+  // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept (I >= J); which thread keeps it in
+  // which of its RB slots is a table built by the host (build_resmap, viekf_capi.hip: 8 x 8 tiles of blocks per (slot, wave)
+  // group, so that the column pair of one feature is published from few groups).  Slot a = 0 of the threads t < N is the
+  // diagonal block (t, t).
   const int tid_ = tid;
   constexpr int NWV = TW / 64;
   const DevParams& prm = *a.dp;
   double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns of P live in LDS for the whole step
   double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
   // (P[body rows, feature cols] is NOT kept: P is symmetric up to rounding, the mirror is written at store time)
-  const int nown = N * (N + 1) / 2;
-  const float rcpN = 1.0f / (float)N;
-  auto blk = [&](int t, int ia, int& I, int& J) -> bool {   // block ia of thread t; false = not owned
-    int idx = t + TW * ia;
-    const bool v = idx < nown;
-    idx = min(idx, nown - 1);             // clamped: every LDS / global read stays in range, results never stored
-    const int d = (int)(((float)idx + 0.5f) * rcpN);   // idx / N (exact: idx < 2^20, the margin 0.5 / N dwarfs the rounding)
-    I = idx - d * N;
-    J = I + d;
-    if (J >= N) J -= N;
-    return v;
+  const int* __restrict__ resmap = a.resmap;
+  auto blk = [&](int t, int ia, int& I, int& J) -> bool {   // block ia of thread t; false = not owned (then I = J = 0: every
+    const int e = resmap[ia * TW + t];                       // LDS / global read stays in range, results are never stored)
+    I = e & 0xff;
+    J = (e >> 8) & 0xff;
+    return (e >> 16) != 0;
   };
   const bool own_diag = tid_ < N;   // slot 0 of this thread is the diagonal block (I, I), I = tid
-  static_assert(TW >= 64, "the diagonal d = 0 must sit in slot 0: TW >= N");
 
   double pb[RB][9];   // pb[a][r*3+s] = P[16+3I+r][16+3J+s]
   {
@@ -241,8 +235,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     //      and k gives the pair (Ut[k], D[k]) -- or two adjacent columns of Gs
     // (many blocks per thread: the Z-row offsets of a block's I and J are packed into one register per block ahead of the
     //  loop -- re-deriving them from the thread index cost as many instructions per k as the arithmetic)
-    int zoff[RB > 4 ? RB : 1];
-    if (RB > 4) {
+    int zoff[RB];
+    {
       const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
@@ -253,19 +247,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     }
     auto contract = [&](int k, auto crossed) {
       constexpr bool CROSS = decltype(crossed)::value;
-      const int tq = opaque(tid_);
 #pragma unroll
       for (int ia = 0; ia < RB; ia++) {
-        const double *zi, *zj;
-        if (RB > 4) {
-          zi = Z + (zoff[ia] & 0xffff) + 2 * k;
-          zj = Z + (zoff[ia] >> 16) + 2 * k;
-        } else {
-          int I, J;
-          blk(tq, ia, I, J);
-          zi = Z + (3 * I) * ZS + 2 * k;
-          zj = Z + (3 * J) * ZS + 2 * k;
-        }
+        const double* zi = Z + (zoff[ia] & 0xffff) + 2 * k;
+        const double* zj = Z + (zoff[ia] >> 16) + 2 * k;
         double2 xv[3], yv[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) xv[r] = lds_ld2(zi + r * ZS);
@@ -397,7 +382,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const int it = tid;
     // ---- (1) feature/feature blocks (registers).  The operand rows of GB blocks are in flight together: all of them with
     //      few blocks per thread; two at a time with many, where holding every block's rows would not fit the register file
-    constexpr int GB = (RB <= 3) ? RB : 2;
+    constexpr int GB = (RB <= 4) ? RB : 2;
     const bool gated = gflag != 0.0;
     const bool run = !gated && nanw == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
     bool fixed = false;
@@ -422,8 +407,12 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
           for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int s = 0; s < 3; s++) {
-              const double t = fma(kI[ig][r].y, wJ[ig][s].y, kI[ig][r].x * wJ[ig][s].x);
-              pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
+              if (ZU && !(r == 2 && s == 2)) {   // Lambda = 1: two multiply-adds instead of three operations
+                pb[ia][r * 3 + s] = fma(-kI[ig][r].y, wJ[ig][s].y, fma(-kI[ig][r].x, wJ[ig][s].x, pb[ia][r * 3 + s]));
+              } else {
+                const double t = fma(kI[ig][r].y, wJ[ig][s].y, kI[ig][r].x * wJ[ig][s].x);
+                pb[ia][r * 3 + s] = fma(-Lff[r * 3 + s], t, pb[ia][r * 3 + s]);
+              }
             }
         }
       }
@@ -437,10 +426,13 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     if (sq.y >= 0 && !(S.dbg & 4)) extract_cols(sq.y, rawdst);
     __builtin_amdgcn_s_setprio(0);
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
+    RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
     __builtin_amdgcn_sched_barrier(0);
     // ---- (3) body columns, in LDS (res_body_items); with few worker waves the tail of the items is the service wave's: it
     //      would only wait at the barrier, the workers are the longer side there
-    res_body_items(S, kP, run, it, TW, 0, 8 * N - res_service_items<NWV>(N), sq.y, rawdst);
+    //      (wave 0 takes the last places in the item order, so that the incomplete final round falls to the other waves: it is
+    //      the longest of the workers whenever its SIMD-mate is the other workgroup's service wave)
+    res_body_items(S, kP, run, (it >= 64) ? it - 64 : it + TW - 64, TW, 0, 8 * N - res_service_items<NWV>(N), sq.y, rawdst);
     if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads.  Element (r, c) and its mirror (c, r) are
                  // owned by different threads; both form  p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own
                  // (equal) copies, so the block stays exactly symmetric without any exchange.
