@@ -328,6 +328,60 @@ bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
       }
     }
   }
+  // Which WAVE a group sits on is still free (a wave sweeps all its slots alike): exchange whole groups between waves while
+  // that lowers, in this order, the largest number of groups any wave has to publish from for one feature (the update's
+  // waves meet at a barrier: the slowest one counts), the sum over the features of that maximum, and the sum of squares.
+  // N = 50 on three waves: at most 4 -> 3 groups; N = 64 on six: 4 -> 2.
+  if (N <= 64) {
+    const int ng = RB * NWV;
+    std::vector<unsigned long long> mask(ng, 0ull);   // features with a block in group (slot, wave) = index slot * NWV + wave
+    auto remask = [&](int g) {
+      unsigned long long mk = 0ull;
+      const int slot = g / NWV, wave = g % NWV;
+      for (int l = 0; l < 64; l++) {
+        const int e = map[(size_t)slot * TW + 64 * wave + l];
+        if (e >> 16) mk |= (1ull << (e & 0xff)) | (1ull << ((e >> 8) & 0xff));
+      }
+      mask[g] = mk;
+    };
+    for (int g = 0; g < ng; g++) remask(g);
+    struct Cost { long mx, summx, sq; bool operator<(const Cost& o) const { return mx != o.mx ? mx < o.mx : (summx != o.summx ? summx < o.summx : sq < o.sq); } };
+    auto cost = [&]() {
+      Cost c{0, 0, 0};
+      for (int f = 0; f < N; f++) {
+        long fm = 0;
+        for (int w = 0; w < NWV; w++) {
+          long cnt = 0;
+          for (int sl = 0; sl < RB; sl++) cnt += (mask[sl * NWV + w] >> f) & 1ull;
+          fm = std::max(fm, cnt);
+          c.sq += cnt * cnt;
+        }
+        c.mx = std::max(c.mx, fm);
+        c.summx += fm;
+      }
+      return c;
+    };
+    auto whole = [&](int g) { return !(g / NWV == 0 && 64 * (g % NWV) < N); };   // (not sharing its lanes with the diagonal blocks)
+    Cost best = cost();
+    for (bool improved = true; improved;) {
+      improved = false;
+      for (int g1 = 0; g1 < ng; g1++)
+        for (int g2 = g1 + 1; g2 < ng; g2++) {
+          if (!whole(g1) || !whole(g2) || g1 % NWV == g2 % NWV) continue;
+          std::swap(mask[g1], mask[g2]);
+          const Cost c = cost();
+          if (c < best) {
+            best = c;
+            improved = true;
+            int* p1 = &map[(size_t)(g1 / NWV) * TW + 64 * (g1 % NWV)];
+            int* p2 = &map[(size_t)(g2 / NWV) * TW + 64 * (g2 % NWV)];
+            for (int l = 0; l < 64; l++) std::swap(p1[l], p2[l]);
+          } else {
+            std::swap(mask[g1], mask[g2]);
+          }
+        }
+    }
+  }
   return true;
 }
 

@@ -176,7 +176,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   const double lraw[3] = {S.lam[rid0], S.lam[rid1], S.lam[rid2]};
   // The rows are dealt by ROLE (a feature lane its three rows, the attitude lane rows 6..8, a linear body lane its one row),
   // so a lane's own rows of K and W -- all that its state correction needs in the next phase -- stay in registers.
-  struct Rows { double2 kA, wA, kB, wB, kC; int bad; };
+  struct Rows { double2 kA, wA, kB, wB, kC, oA, oB, oC; int bad; };   // (oX: the row's operand of next_rows -- K for a feature row, W for a body row)
   const bool three = isfeat || isatt;   // lanes with three distinct rows (the others would write the same row three times)
   const int ridv[3] = {rid0, rid1, rid2};
   auto gain_rows = [&](const Meas& q, int nanword, int gateword, const double2 (&pr)[3], double* Kd, Rows& o) {
@@ -200,6 +200,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       if (PRIMARY) sm[gateword] = q.gate;
     }
     o.kA = kv[0]; o.wA = wv[0]; o.kB = kv[1]; o.wB = wv[1]; o.kC = kv[2]; o.bad = bad;
+    o.oA = isfeat ? kv[0] : wv[0]; o.oB = isfeat ? kv[1] : wv[1]; o.oC = isfeat ? kv[2] : wv[2];
   };
   // This lane's rows of the NEXT measurement's column pair: published by the worker waves one phase ago (buffer `rb`), as they
   // stood BEFORE the update being swept in this phase -- which is applied here (`swept`; gains Kc / Wc, this lane's own K rows
@@ -207,23 +208,32 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   // body rows k take K of the column's feature and W_k, as the block sweep and the body-column sweep do.  Everything this
   // needs is complete at the top of a phase, so it runs there, off the critical path.
   const double lfz[3] = {lz0, lz1, uniform_f64(a.lambda[18])};
-  auto next_rows = [&](int rb, bool swept, int slot, const double* Kc, const double2 (&k3)[3], double2 (&o)[3]) {
+  // The dot products are  K_i . W_j  for a feature row i (own K row, the column feature's W row -- uniform over the lanes) and
+  // K_j . W_k  for a body row k (the column feature's K row -- uniform --, own W row): one form  own . uni  with the lane's own
+  // operand kept from gain_rows (Rows::oX) and the uniform one read out of the registers of the column feature's lane (single
+  // service wave; v_readlane, no LDS round trip on the wave that closes every update).  Two service waves: the body wave has no
+  // feature lanes, it reads the column feature's K rows from the gain buffer.
+  auto next_rows = [&](int rb, bool swept, int slot, const double* Kc, const Rows& cr, double2 (&o)[3]) {
     const double* raw = S.Praw + rb * 2 * n;
-    const double* Wc = Kc + 2 * n;
-    const double2 ka = lds_ld2(Kc + 2 * (16 + 3 * slot)), kb2 = lds_ld2(Kc + 2 * (16 + 3 * slot + 1));
-    const double2 wa = lds_ld2(Wc + 2 * (16 + 3 * slot)), wb2 = lds_ld2(Wc + 2 * (16 + 3 * slot + 1));
+    double2 st[3];
+    st[0] = lds_ld2(raw + 2 * ridv[0]);      // (P[i][j0], P[i][j0+1]) before the update
+    if (three) { st[1] = lds_ld2(raw + 2 * ridv[1]); st[2] = lds_ld2(raw + 2 * ridv[2]); }
+    double2 ua, ub;                           // the uniform operands for columns j0, j0+1
+    if (ROLE == 2) {
+      ua = lds_ld2(Kc + 2 * (16 + 3 * slot)); ub = lds_ld2(Kc + 2 * (16 + 3 * slot + 1));
+    } else {
+      const double2 ka = make_double2(bcast(cr.kA.x, slot), bcast(cr.kA.y, slot)), kb2 = make_double2(bcast(cr.kB.x, slot), bcast(cr.kB.y, slot));
+      const double2 wa = make_double2(bcast(cr.wA.x, slot), bcast(cr.wA.y, slot)), wb2 = make_double2(bcast(cr.wB.x, slot), bcast(cr.wB.y, slot));
+      ua = isfeat ? wa : ka; ub = isfeat ? wb2 : kb2;
+    }
+    const double2 own[3] = {cr.oA, cr.oB, cr.oC};
     auto one = [&](int u) {
-      const double2 st = lds_ld2(raw + 2 * ridv[u]);      // (P[i][j0], P[i][j0+1]) before the update
-      double r0 = st.x, r1 = st.y;
+      double r0 = st[u].x, r1 = st[u].y;
       if (swept) {
         const double lamk = isfeat ? lfz[u] : lraw[u];
         const double La = partial ? (lamk + lz0 - lz0 * lamk) : 1.0, Lb = partial ? (lamk + lz1 - lz1 * lamk) : 1.0;
-        const double2 wk = lds_ld2(Wc + 2 * ridv[u]);
-        // (operands by role, no divergence: K_i . W_j0 | K_j0 . W_k)
-        const double2 xa = isfeat ? k3[u] : ka, ya = isfeat ? wa : wk;
-        const double2 xb = isfeat ? k3[u] : kb2, yb = isfeat ? wb2 : wk;
-        r0 = fma(-La, fma(xa.y, ya.y, xa.x * ya.x), r0);
-        r1 = fma(-Lb, fma(xb.y, yb.y, xb.x * yb.x), r1);
+        r0 = fma(-La, fma(own[u].y, ua.y, own[u].x * ua.x), r0);
+        r1 = fma(-Lb, fma(own[u].y, ub.y, own[u].x * ub.x), r1);
       }
       o[u] = make_double2(r0, r1);
     };
@@ -283,10 +293,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const bool bad = crow.bad != 0 || (ROLE != 0 && sm[44 + cnt % 3 + (ROLE == 2 ? 0 : 8)] != 0.0);
     const double r0 = cur.r0, r1 = cur.r1;
     double2 prn[3] = {};
-    if (slot_next >= 0) {
-      const double2 k3[3] = {kA, kB, kC};
-      next_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), slot_next, kP, k3, prn);
-    }
+    if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
     const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;

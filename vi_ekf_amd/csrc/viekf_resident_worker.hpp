@@ -65,18 +65,26 @@ __device__ __forceinline__ void res_body_items(const ResShared& S, const double*
                                                int first, int last, int slot2, double* rawdst) {
   const double* wP = kP + 2 * S.n;
   double* Pbc = S.Pbc;
+  // (the caller count is a multiple of 8, so a caller's body-column pair j2 is the same for all its items: W of those two
+  //  columns and their Lambda entries are read once, not per item)
+  const int j2 = ((first + id) & 7) * 2;
+  double2 cw0 = {}, cw1 = {}, cl[3] = {};
+  if (run) {
+    cw0 = lds_ld2(wP + 2 * j2);
+    cw1 = lds_ld2(wP + 2 * j2 + 2);
+#pragma unroll
+    for (int q = 0; q < 3; q++) cl[q] = lds_ld2(S.Lbc + 16 * q + j2);
+  }
 #pragma unroll 1
   for (int item = first + id; item < last; item += nthreads) {
-    const int g = item >> 3, j2 = (item & 7) * 2;
+    const int g = item >> 3;
     double2 cpv[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) cpv[q] = lds_ld2(Pbc + (3 * g + q) * 16 + j2);
     if (run) {
-      const double2 cw0 = lds_ld2(wP + 2 * j2);
-      const double2 cw1 = lds_ld2(wP + 2 * j2 + 2);
-      double2 cki[3], cl[3];
+      double2 cki[3];
 #pragma unroll
-      for (int q = 0; q < 3; q++) { cki[q] = lds_ld2(kP + 2 * (16 + 3 * g + q)); cl[q] = lds_ld2(S.Lbc + 16 * q + j2); }
+      for (int q = 0; q < 3; q++) cki[q] = lds_ld2(kP + 2 * (16 + 3 * g + q));
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         cpv[q].x = fma(-cl[q].x, fma(cki[q].y, cw0.y, cki[q].x * cw0.x), cpv[q].x);
