@@ -858,6 +858,17 @@ int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
   return VIEKF_OK;
 }
 
+// diagnostic hook (not part of include/viekf.h; host arithmetic only, no device needed): the fused-step kernel's block
+// ownership map for n_feat features on `nw` worker waves with `rb` slots per thread -> out[rb * 64 * nw] entries
+// I | J << 8 | owned << 16; -1 when the blocks do not fit.  tests/test_resmap_cpu.py checks its invariants.
+int viekf_debug_build_resmap(int n_feat, int rb, int nw, int32_t* out) {
+  std::vector<int> map;
+  if (n_feat < 1 || rb < 1 || nw < 1 || !out) return -1;
+  if (n_feat * (n_feat + 1) / 2 > rb * nw * 64 || !build_resmap(n_feat, rb, nw, map)) return -1;
+  for (size_t i = 0; i < map.size(); i++) out[i] = map[i];
+  return 0;
+}
+
 int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem where) {
   if (int rc = check_batch(b)) return rc;
   if (b->upper_stale) { HIP_TRY(hipSetDevice(b->device)); if (int rc = ensure_full_P(b)) return rc; }
