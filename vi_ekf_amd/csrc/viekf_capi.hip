@@ -218,7 +218,7 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 }
 
 // Resident instances <RB, NW>: NW worker waves (+1 service wave) per workgroup.  Symmetric ownership: the N (N + 1) / 2 owned
-// 3x3 blocks are dealt round-robin to the NW * 64 worker threads, at most RB per thread.
+// 3x3 blocks are dealt to the NW * 64 worker threads by build_resmap below, at most RB per thread.
 struct ResInst { int RB, NW, nmin, nmax, max_lds_kb, NS; };   // NS: service waves (2: the body lanes on a wave of their own)
 const ResInst kResInst[] = {
     {3, 2, 1, 25, 80, 1},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain

@@ -9,8 +9,8 @@
 //         this file                   prologue (state, measurement table) and the kernel
 //
 // Ownership: the 3N x 3N feature part of P is a grid of 3x3 blocks (I,J).  P is symmetric, so of every
-// unordered pair {I,J} only ONE block is kept, on wrapped diagonals J = (I + d) mod N, d = 0..N/2; the N (N + 1) / 2 owned
-// blocks are numbered idx = d N + I and dealt round-robin to the worker threads (idx = t + TW a, a < RB).  The 16 body columns
+// unordered pair {I,J} only ONE block is kept (I >= J); which worker thread keeps it in which of its RB register slots is a
+// table built by the host (8 x 8 tiles of blocks per 64-lane group: build_resmap, viekf_capi.hip).  The 16 body columns
 // P[:,0:16] live in LDS for the whole step (the body rows are their mirror).  A rank-2 sweep needs K for the block's rows and
 // W for its columns; the propagation Phi P Phi^T + Gd Qu Gd^T is a register-tiled K = 24 contraction over one record per
 // row (viekf_resident_common.hpp).  lambda_feat is the same for every feature slot (vi_ekf.cpp:139-144), so the
