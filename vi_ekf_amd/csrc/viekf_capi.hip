@@ -221,6 +221,9 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
 // 3x3 blocks are dealt to the NW * 64 worker threads by build_resmap below, at most RB per thread.
 struct ResInst { int RB, NW, nmin, nmax, max_lds_kb, NS; };   // NS: service waves (2: the body lanes on a wave of their own)
 const ResInst kResInst[] = {
+    {2, 1, 1, 15, 40, 1},   // the reference's own sizes (NUM_FEATURES 12, params 20 -> here up to 15): ONE worker wave + the service
+                     // wave, four 128-thread workgroups per CU (LDS <= 40 KB) -- a small filter's step is its update chain's latency,
+                     // so the CU is filled with chains
     {3, 2, 1, 25, 80, 1},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
                      // runs under the other's sweeps
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
@@ -396,10 +399,11 @@ res_kernel_t res_pick(bool multi, bool zu) {
 }
 res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
   switch (inst) {
-    case 0: return res_pick<3, 2, 1>(multi, zu);
-    case 1: return res_pick<7, 3, 1>(multi, zu);
-    case 2: return res_pick<3, 7, 1>(multi, zu);
-    case 3: return res_pick<6, 6, 2>(multi, zu);
+    case 0: return res_pick<2, 1, 1>(multi, zu);
+    case 1: return res_pick<3, 2, 1>(multi, zu);
+    case 2: return res_pick<7, 3, 1>(multi, zu);
+    case 3: return res_pick<3, 7, 1>(multi, zu);
+    case 4: return res_pick<6, 6, 2>(multi, zu);
   }
   return nullptr;
 }
@@ -420,6 +424,7 @@ int setup_resident(viekf_batch* b) {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
       if (b->B <= cus) continue;
+      if (r.max_lds_kb <= 40 && b->B <= 2 * cus) continue;   // (four per CU: only when two per CU would leave filters waiting)
     }
     std::vector<int> map;
     if (!build_resmap(b->N, r.RB, r.NW, map)) continue;

@@ -436,16 +436,17 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- (3) body columns, in LDS (res_body_items); with few worker waves the tail of the items is the service wave's: it
-    //      would only wait at the barrier, the workers are the longer side there
-    //      (wave 0 takes the last places in the item order, so that the incomplete final round falls to the other waves: it is
-    //      the longest of the workers whenever its SIMD-mate is the other workgroup's service wave)
+    // ---- (3) body columns, in LDS (res_body_items).  Wave 0 takes the last places in the item order, so that the incomplete
+    //      final round falls to the other waves: it is the longest of the workers whenever its SIMD-mate is the other workgroup's
+    //      service wave.
     res_body_items(S, kP, run, (it >= 64) ? it - 64 : it + TW - 64, TW, 0, 8 * N - res_service_items<NWV>(N), sq.y, rawdst);
-    if (run) {   // body block: 2 adjacent elements per thread, on the top 128 threads.  Element (r, c) and its mirror (c, r) are
-                 // owned by different threads; both form  p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own
-                 // (equal) copies, so the block stays exactly symmetric without any exchange.
-      const int ib = it - (TW - 128);
-      if (ib >= 0) {
+    if (run) {   // body block: 2 adjacent elements per task, 128 tasks on the top 128 threads (a single worker wave: two tasks
+                 // per thread).  Element (r, c) and its mirror (c, r) are owned by different tasks; both form
+                 // p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own (equal) copies, so the block stays exactly
+                 // symmetric without any exchange.
+      constexpr int BBT = (TW >= 128) ? 128 : TW;
+#pragma unroll
+      for (int ib = it - (TW - BBT); ib >= 0 && ib < 128; ib += BBT) {
         const int br = ib >> 3, bc2 = (ib & 7) * 2;
         double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
         const double blr = S.lam[br];
