@@ -94,3 +94,10 @@ def test_two_filters_per_workgroup_sizes_between():
     """B=1024 at feature counts either side of the instance boundaries"""
     run_full(1024, 26, 2, [0, 300, 1023])
     run_full(1024, 49, 2, [0, 512, 1023])
+
+
+@pytest.mark.parametrize("N", [1, 3, 12, 15])
+def test_four_per_cu_instance_small_filters(N):
+    """B=1024 > 2 x 256 CUs, N <= 15: the <2,1> instance (ONE worker wave + the service wave, four 128-thread workgroups per CU;
+    the reference's own sizes: NUM_FEATURES 12, include/vi_ekf.h:39-45)"""
+    run_full(1024, N, 3, [0, 1, 255, 256, 511, 512, 767, 1022, 1023])
