@@ -101,3 +101,8 @@ def test_four_per_cu_instance_small_filters(N):
     """B=1024 > 2 x 256 CUs, N <= 15: the <2,1> instance (ONE worker wave + the service wave, four 128-thread workgroups per CU;
     the reference's own sizes: NUM_FEATURES 12, include/vi_ekf.h:39-45)"""
     run_full(1024, N, 3, [0, 1, 255, 256, 511, 512, 767, 1022, 1023])
+
+
+def test_features_on_both_service_waves_full_batch():
+    """B=1024, N=70: the <7,6> instance (features 64.. on the body wave's lanes; the measurement list crosses the 64 per launch)"""
+    run_full(1024, 70, 2, [0, 255, 256, 1023])

@@ -71,7 +71,9 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
                                               (3, 1, 4, 2), (3, 2, 4, 2), (4, 8, 4, 2), (4, 12, 5, 2), (3, 17, 3, 2), (2, 25, 3, 2),
                                               (2, 33, 2, 2), (2, 41, 2, 2), (2, 49, 2, 2), (3, 50, 2, 2),
                                               # N + 14 > 64 lanes: the body lanes on a second service wave (<6,6>, two service waves)
-                                              (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0), (2, 63, 2, 2), (2, 59, 1, 2)])
+                                              (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0), (2, 63, 2, 2), (2, 59, 1, 2),
+                                              # more than 64 features: features 64.. on the body wave's lanes (<7,6>, N <= 72)
+                                              (2, 65, 2, 2), (2, 70, 2, 2), (2, 72, 2, 0), (2, 69, 1, 2)])
 def test_step_parity(B, N, steps, kernel):
     sc = scene.make_scene(B, N, steps, seed=100 + N)
     x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)
@@ -136,7 +138,7 @@ def test_propagate_only_partial_features_and_qx(N, nfeat):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2)])
+@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2)])
 def test_update_gating_nan_invalid_and_full_update(N, kernel):
     """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update; both kernel
     families (the grouped streaming update has its own gate / skip paths inside a group)"""
@@ -177,7 +179,7 @@ def test_update_gating_nan_invalid_and_full_update(N, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2)])
+@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2), (68, 2)])
 def test_fix_depth_inside_the_updates(N, kernel):
     """fix_depth after an UPDATE (vi_ekf_meas.cpp:271): features that start just in front of the camera's infinity with a
     large depth variance correlated with the bearing are pushed to rho < 0 by noisy pixels -- the reset, the P(rho,rho) edit and the flag, in the middle

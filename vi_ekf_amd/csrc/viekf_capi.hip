@@ -229,6 +229,7 @@ const ResInst kResInst[] = {
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
+    {7, 6, 65, 72, 160, 2},   // ... and features 64.. on the body wave's free lanes; 7 blocks per thread is what the registers hold
     // (<4, 5> -- two 384-thread workgroups per CU, three waves per SIMD at <= 168 VGPRs -- measured 32 % slower: dropped)
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
@@ -335,15 +336,16 @@ bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
   // that lowers, in this order, the largest number of groups any wave has to publish from for one feature (the update's
   // waves meet at a barrier: the slowest one counts), the sum over the features of that maximum, and the sum of squares.
   // N = 50 on three waves: at most 4 -> 3 groups; N = 64 on six: 4 -> 2.
-  if (N <= 64) {
+  if (N <= 128) {
+    typedef unsigned __int128 fmask_t;
     const int ng = RB * NWV;
-    std::vector<unsigned long long> mask(ng, 0ull);   // features with a block in group (slot, wave) = index slot * NWV + wave
+    std::vector<fmask_t> mask(ng, (fmask_t)0);   // features with a block in group (slot, wave) = index slot * NWV + wave
     auto remask = [&](int g) {
-      unsigned long long mk = 0ull;
+      fmask_t mk = 0;
       const int slot = g / NWV, wave = g % NWV;
       for (int l = 0; l < 64; l++) {
         const int e = map[(size_t)slot * TW + 64 * wave + l];
-        if (e >> 16) mk |= (1ull << (e & 0xff)) | (1ull << ((e >> 8) & 0xff));
+        if (e >> 16) mk |= ((fmask_t)1 << (e & 0xff)) | ((fmask_t)1 << ((e >> 8) & 0xff));
       }
       mask[g] = mk;
     };
@@ -355,7 +357,7 @@ bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
         long fm = 0;
         for (int w = 0; w < NWV; w++) {
           long cnt = 0;
-          for (int sl = 0; sl < RB; sl++) cnt += (mask[sl * NWV + w] >> f) & 1ull;
+          for (int sl = 0; sl < RB; sl++) cnt += (long)((mask[sl * NWV + w] >> f) & 1);
           fm = std::max(fm, cnt);
           c.sq += cnt * cnt;
         }
@@ -404,6 +406,7 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
     case 2: return res_pick<7, 3, 1>(multi, zu);
     case 3: return res_pick<3, 7, 1>(multi, zu);
     case 4: return res_pick<6, 6, 2>(multi, zu);
+    case 5: return res_pick<7, 6, 2>(multi, zu);
   }
   return nullptr;
 }

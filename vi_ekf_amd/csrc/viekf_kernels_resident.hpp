@@ -52,7 +52,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
       const double lk = a.lambda[tid & 15], lq = a.lambda[16 + (tid >> 4)];
       S.Lbc[tid] = a.dp->use_partial_update ? (lk + lq - lq * lk) : 1.0;
     }
-    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; S.sm[32] = 0.0; S.sm[33] = 0.0; S.sm[52] = 0.0; S.sm[53] = 0.0; S.sm[54] = 0.0; }
+    if (tid == 0) { S.sm[42] = (do_prop & 1) ? dt_all[b] : 0.0; S.sm[40] = 0.0; S.sm[41] = 0.0; S.sm[44] = 0.0; S.sm[45] = 0.0; S.sm[46] = 0.0; S.sm[49] = 0.0; S.sm[50] = 0.0; S.sm[51] = 0.0; S.sm[32] = 0.0; S.sm[33] = 0.0; S.sm[52] = 0.0; S.sm[53] = 0.0; S.sm[54] = 0.0; S.sm[36] = 0.0; S.sm[37] = 0.0; }
     for (int mm_ = tid; mm_ < M; mm_ += T) {
       const int slot = slot_all[(long)b * m_stride + mm_];
       const double z0 = z_all[((long)b * m_stride + mm_) * 2], z1 = z_all[((long)b * m_stride + mm_) * 2 + 1];

@@ -6,11 +6,11 @@ namespace viekf {
 
 // ---- the service wave: everything that is not a sweep over P --------------------------------------
 // ROLE 0: the one service wave of a workgroup (N + 14 <= 64 lanes: a lane per feature and 14 body lanes).  More features than
-// that split the roles over TWO service waves: ROLE 1 = the feature lanes (and everything a single service wave does besides:
-// dynamics, prediction, result codes, the state store), ROLE 2 = the 14 body lanes on a wave of their own.  The body wave
-// receives each measurement's {Hb, residual, S^-1, gate} from the feature wave through an LDS mailbox (polled: the feature
-// wave never waits for the body wave other than at the barriers); each wave writes the gain rows and the NaN-guard word of
-// its own rows.
+// that split the roles over TWO service waves: ROLE 1 = the lanes of features 0..63 (and everything a single service wave does
+// besides: dynamics, result codes, the state store), ROLE 2 = the 14 body lanes on a wave of their own -- and, past 64 features
+// (N <= 114 by lanes; the register file ends the family at N = 72), features 64.. on its lanes 14...  A measurement is
+// predicted by the wave that holds its feature; the other one receives {Hb, residual, S^-1, gate} through an LDS mailbox
+// (polled; bounded); each wave writes the gain rows, the NaN-guard word and the fix_depth mailbox flag of its own rows.
 template <int T, bool MP, int ROLE = 0>
 __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared& S, int lane, int nww,
                                             const double* __restrict__ u_all, const double* __restrict__ dt_all,
@@ -104,18 +104,23 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   //   lane N+j, j = 0..5   : body row j            (p, v)          linear state x[j]
   //   lane N+6             : body rows 6,7,8       (attitude)      quaternion x[6..9], right-multiplied
   //   lane N+j, j = 7..13  : body row j+2 = 9..15  (b_a, b_g, mu)  linear state x[j+3]
-  const int jb = (ROLE == 2) ? lane : ((ROLE == 1) ? -1 : lane - N);
-  const bool isfeat = PRIMARY && lane < N;
+  // feature of this lane (or -1): ROLE 0 / 1: the lane number; ROLE 2: features 64.. on the lanes after the 14 body lanes
+  const int fid = (ROLE == 2) ? ((lane >= 14 && 50 + lane < N) ? 50 + lane : -1) : ((lane < N) ? lane : -1);
+  const int jb = (ROLE == 2) ? ((lane < 14) ? lane : -1) : ((ROLE == 1) ? -1 : lane - N);
+  const bool isfeat = fid >= 0;
+  // does this wave hold feature `slot` (it then predicts its measurement), and on which lane
+  auto holds = [&](int slot) -> bool { return ROLE == 0 || ((ROLE == 1) == (slot < 64)); };
+  auto lane_of = [&](int slot) -> int { return (ROLE == 2) ? slot - 50 : slot; };
   const bool isatt = jb == 6;
-  const bool hasq = (isfeat && lane < len) || isatt;
-  const bool haslin = (isfeat && lane < len) || (jb >= 0 && jb < 14 && jb != 6);
+  const bool hasq = (isfeat && fid < len) || isatt;
+  const bool haslin = (isfeat && fid < len) || (jb >= 0 && jb < 14 && jb != 6);
   int rid0, rid1, rid2;
-  if (isfeat) { rid0 = 16 + 3 * lane; rid1 = rid0 + 1; rid2 = rid0 + 2; }
+  if (isfeat) { rid0 = 16 + 3 * fid; rid1 = rid0 + 1; rid2 = rid0 + 2; }
   else if (isatt) { rid0 = 6; rid1 = 7; rid2 = 8; }
   else { const int r = (jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 2 : 0)); rid0 = rid1 = rid2 = r; }
   const bool rowlane = isfeat || (jb >= 0 && jb < 14);   // this lane owns rows of K / W (the others only tag along)
-  double* qptr = isfeat ? (xs + xZ + 5 * lane) : (xs + xATT);
-  double* linptr = isfeat ? (xs + xZ + 5 * lane + 4) : (xs + ((jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0))));
+  double* qptr = isfeat ? (xs + xZ + 5 * fid) : (xs + xATT);
+  double* linptr = isfeat ? (xs + xZ + 5 * fid + 4) : (xs + ((jb < 0) ? 0 : ((jb < 6) ? jb : ((jb < 14) ? jb + 3 : 0))));
   // (wave-uniform constants of the update loop are forced into SGPRs: as VGPR pairs they were a fifth of the loop's live set)
   const double rho_reset = uniform_f64(1.0 / (2.0 * prm.min_depth));
   // Lambda of the zeta-zeta 2x2 block (lambda_feat[0], lambda_feat[1])
@@ -130,7 +135,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   RES_STAMP(S, lane == 0, 9);
   __syncthreads();  // Bp : the workers published Pd (diagonal zeta blocks) and the first measurement's columns
   double pf00 = 0.0, pf01 = 0.0, pf10 = 0.0, pf11 = 0.0;
-  if (isfeat) { const double* pd = S.Pd + 4 * lane; pf00 = pd[0]; pf01 = pd[1]; pf10 = pd[2]; pf11 = pd[3]; }
+  if (isfeat) { const double* pd = S.Pd + 4 * fid; pf00 = pd[0]; pf01 = pd[1]; pf10 = pd[2]; pf11 = pd[3]; }
   // prediction + innovation of measurement mm (slot == this lane's feature) into mailbox half `hh`, from registers
   // Uniform per-measurement values {Hb, residual, S^-1, gate}: computed by the lane of the measured feature, handed to the
   // whole wave with v_readlane (they land in SGPRs; an LDS mailbox cost a store, a wave-level sync and a load on the
@@ -219,11 +224,15 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     st[0] = lds_ld2(raw + 2 * ridv[0]);      // (P[i][j0], P[i][j0+1]) before the update
     if (three) { st[1] = lds_ld2(raw + 2 * ridv[1]); st[2] = lds_ld2(raw + 2 * ridv[2]); }
     double2 ua, ub;                           // the uniform operands for columns j0, j0+1
-    if (ROLE == 2) {
-      ua = lds_ld2(Kc + 2 * (16 + 3 * slot)); ub = lds_ld2(Kc + 2 * (16 + 3 * slot + 1));
-    } else {
-      const double2 ka = make_double2(bcast(cr.kA.x, slot), bcast(cr.kA.y, slot)), kb2 = make_double2(bcast(cr.kB.x, slot), bcast(cr.kB.y, slot));
-      const double2 wa = make_double2(bcast(cr.wA.x, slot), bcast(cr.wA.y, slot)), wb2 = make_double2(bcast(cr.wB.x, slot), bcast(cr.wB.y, slot));
+    if (holds(slot)) {                        // (wave-uniform) the column feature's rows are in this wave's registers
+      const int sl = lane_of(slot);
+      const double2 ka = make_double2(bcast(cr.kA.x, sl), bcast(cr.kA.y, sl)), kb2 = make_double2(bcast(cr.kB.x, sl), bcast(cr.kB.y, sl));
+      const double2 wa = make_double2(bcast(cr.wA.x, sl), bcast(cr.wA.y, sl)), wb2 = make_double2(bcast(cr.wB.x, sl), bcast(cr.wB.y, sl));
+      ua = isfeat ? wa : ka; ub = isfeat ? wb2 : kb2;
+    } else {                                  // the other service wave's: from the gain buffer it wrote before the barrier
+      const double* Wc = Kc + 2 * n;
+      const double2 ka = lds_ld2(Kc + 2 * (16 + 3 * slot)), kb2 = lds_ld2(Kc + 2 * (16 + 3 * slot + 1));
+      const double2 wa = lds_ld2(Wc + 2 * (16 + 3 * slot)), wb2 = lds_ld2(Wc + 2 * (16 + 3 * slot + 1));
       ua = isfeat ? wa : ka; ub = isfeat ? wb2 : kb2;
     }
     const double2 own[3] = {cr.oA, cr.oB, cr.oC};
@@ -240,7 +249,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     one(0);
     if (three) { one(1); one(2); }
     else { o[1] = o[0]; o[2] = o[0]; }
-    if (isfeat && lane == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
+    if (isfeat && fid == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
   };
   // two service waves: the measurement's uniform values cross from the feature wave to the body wave through sm[16 mb ..],
   // published by a sequence number in sm[32 + mb] (an int; each mailbox sees increasing numbers)
@@ -269,9 +278,11 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   Meas cur = {}, nxt = {};
   Rows crow = {}, nrow = {};
   if (m < M) {
-    if (PRIMARY) predict(f1, f2, fz, m, __builtin_amdgcn_readfirstlane(S.mslot[m]), cur);
-    if (ROLE == 1) send(cur, 0, 1);
-    if (ROLE == 2) recv(cur, 0, 1);
+    {
+      const int s0 = __builtin_amdgcn_readfirstlane(S.mslot[m]);
+      if (holds(s0)) { predict(f1, f2, fz, m, lane_of(s0), cur); if (ROLE != 0) send(cur, 0, 1); }
+      else recv(cur, 0, 1);
+    }
     double2 pr0[3];
 #pragma unroll
     for (int u = 0; u < 3; u++) pr0[u] = lds_ld2(S.Praw + 2 * ridv[u]);   // (the first raw columns: buffer 0, published before Bp)
@@ -330,32 +341,34 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
-    if (PRIMARY && lane == 0) sm[40 + par] = 0.0;
+    // (fix_depth mailbox flag: one word per service wave -- [40 + par] / [36 + par] -- each wave clears and sets its own)
+    constexpr int FIXW = (ROLE == 2) ? 36 : 40;
+    if (lane == 0) sm[FIXW + par] = 0.0;
     // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238): almost never fires -- one wave-wide test
-    const bool odd_depth = !gated && isfeat && lane < len && !(lin >= 0.0 && lin <= 1e2);
+    const bool odd_depth = !gated && isfeat && fid < len && !(lin >= 0.0 && lin <= 1e2);
     if (__any(odd_depth)) {
       if (odd_depth) {
         double rho = lin;
         if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
         if (rho < 0.0) {
           const double err = rho_reset - rho;
-          S.fixadd[par * N + lane] = err * err;
-          sm[40 + par] = 1.0;
+          S.fixadd[par * N + fid] = err * err;
+          sm[FIXW + par] = 1.0;
           rho = rho_reset;
           flag |= FLAG_NEGDEPTH;
         } else if (rho > 1e2) {
-          S.fixset[par * N + lane] = 1.0;
-          sm[40 + par] = 1.0;
+          S.fixset[par * N + fid] = 1.0;
+          sm[FIXW + par] = 1.0;
           rho = rho_reset;
         }
         lin = rho;
       }
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 2);
-    if (slot_next >= 0) {   // next measurement, from registers
-      if (PRIMARY) predict(f1, f2, fz, mnext, __builtin_amdgcn_readfirstlane(slot_next), nxt);
-      if (ROLE == 1) send(nxt, (cnt + 1) & 1, cnt + 2);
-      if (ROLE == 2) recv(nxt, (cnt + 1) & 1, cnt + 2);
+    if (slot_next >= 0) {   // next measurement, from registers, on the wave that holds its feature
+      const int sn = __builtin_amdgcn_readfirstlane(slot_next);
+      if (holds(sn)) { predict(f1, f2, fz, mnext, lane_of(sn), nxt); if (ROLE != 0) send(nxt, (cnt + 1) & 1, cnt + 2); }
+      else recv(nxt, (cnt + 1) & 1, cnt + 2);
     }
     if (PRIMARY && result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);

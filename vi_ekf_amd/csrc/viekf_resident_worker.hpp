@@ -287,7 +287,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
     for (int e = tk; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
-    if (MP && kp + 1 < nkp && own_diag && tid_ < len && S.sm[40 + (par ^ 1)] != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
+    if (MP && kp + 1 < nkp && own_diag && tid_ < len && (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]) != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
       const int mb = par ^ 1, I = tid_;
       const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
       if (ad != 0.0) { pb[0][8] += ad; S.fixadd[mb * N + I] = 0.0; }
@@ -347,7 +347,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // produced inside its own phase: no hand-shake, no polling, and the publishing sits off every critical path.
   int2 sq = S.mseq[min(m, MCAP - 1)];
   if (m < S.M) {
-    apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+    apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
     const int s0 = S.mslot[m];
     extract_cols(s0, S.Praw);                                   // first measurement: buffer 0
     if (sq.y >= 0) extract_cols(sq.y, S.Praw + 2 * n);          // second one: buffer 1
@@ -381,7 +381,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const double* kP = (cnt & 1) ? S.Z : S.Kt;
     const double* wP = kP + 2 * n;
     __builtin_amdgcn_s_setprio(1);
-    const double fixpending = S.sm[40 + (par ^ 1)];   // posted before the barrier by the service wave
+    const double fixpending = (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]);   // posted before the barrier by the service wave
     const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
     const double nanw = S.sm[44 + cnt % 3] + S.sm[52 + cnt % 3];   // (the second word: a second service wave's rows)
     sq = S.mseq[min(mnext, MCAP - 1)];                 // next iteration's table entry (static data)
@@ -473,7 +473,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     it_++;
     m = mnext;
   }
-  apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+  apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
   RES_STAMP(S, tid == 0, 72);
   __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
 
