@@ -310,7 +310,7 @@ def test_wide_p_streaming_family(N, M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2)])
+@pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2), (66, 90, 2)])
 def test_more_measurements_than_one_launch_holds(N, M, kernel):
     """M > 64 measurements per step (the fused kernel takes 64 per launch: vi_ekf_amd chunks, P makes one extra HBM round
     trip per chunk), with repeated and skipped (-1) slots, against the oracle applying them one by one"""

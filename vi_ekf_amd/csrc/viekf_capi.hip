@@ -457,7 +457,7 @@ int dbg_bits() {
 
 bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family != 1; }
 
-// one launch handles at most MCAP measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
+// one launch handles at most res_mcap(N) measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
                     double* P_out = nullptr, int KP = 1) {
@@ -470,7 +470,8 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   const ResInst& r = kResInst[b->res_inst];
   int m0 = 0;
   do {
-    const int mc = (M - m0 < MCAP) ? (M - m0) : MCAP;
+    const int cap = res_mcap(b->N);
+    const int mc = (M - m0 < cap) ? (M - m0) : cap;
     hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1, b->res_zu), dim3(b->B), dim3((r.NW + r.NS) * 64), b->res_lds, b->stream, a, b->res_TR,
                        b->res_TC, ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,

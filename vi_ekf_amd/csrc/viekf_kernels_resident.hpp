@@ -42,7 +42,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
-  S.N = a.N; S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
+  S.N = a.N; S.mcap = res_mcap(a.N); S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
   {
     const double* xg = a.x + (long)b * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   }
   RES_STAMP(S, tid == 0, 62);
   __syncthreads();
-  for (int mm_ = tid; mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= MCAP)
+  for (int mm_ = tid; mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= res_mcap(N))
     int nx = mm_ + 1;
     while (nx < M && S.mslot[nx] < 0) nx++;
     S.mseq[mm_] = make_int2(nx, nx < M ? S.mslot[nx] : -1);

@@ -21,6 +21,10 @@ namespace viekf {
 constexpr int ZK = 9;    // rank of the feature/body coupling
 constexpr int ZS = 26;   // row stride of Z: 6 ZS = 28 (mod 64 dwords), consecutive features land on distinct 16-byte bank groups
 
+// measurements per launch (the host chunks longer lists: P then makes one more HBM round trip per chunk): a frame that measures
+// every feature once fits one launch.  (64 up to 64 features: the headline instance is within 740 bytes of its 80 KB.)
+__host__ __device__ inline int res_mcap(int N) { return N > 64 ? 80 : 64; }
+
 struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
   int xs, Kt, Wt, Praw, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, Mbb, Gdb, Pbb, T16, xdb, ctx, Pbc, PhibbT, Pd, PsiP, Pi, Xi, AvG, Lbc, mslot, mseq, mz, mR, img_len, total;
   __host__ __device__ ResLds(int N, int n, int nxs) {
@@ -52,7 +56,8 @@ struct ResLds {  // LDS carve-up in doubles, shared by host (size) and device (o
     ctx = take((int)((sizeof(BodyCtx) + 7) / 8));
     Pbc = take(nf * 16);
     Lbc = take(48);   // Lambda of (feature row q, body column k): [3][16]
-    mslot = take(32); mseq = take(64); mz = take(128); mR = take(256);   // MCAP = 64 measurements per launch
+    const int mc = res_mcap(N);   // measurements per launch
+    mslot = take(mc / 2); mseq = take(mc); mz = take(2 * mc); mR = take(4 * mc);
     total = o;
   }
 };
@@ -111,16 +116,15 @@ __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-unif
 #define RES_STAMP(S_, who, idx) do {} while (0)
 #endif
 
-constexpr int MCAP = 64;  // measurements per launch (the host chunks longer lists)
 typedef __attribute__((address_space(3))) volatile int lds_vint_t;
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles
   double *xs, *Kt, *Wt, *Praw, *lam, *sm, *fixadd, *fixset, *Z, *phiff, *Abb, *Gb, *Phibb, *Mbb, *Gdb, *Pbb, *T16,
       *xdb, *Pbc, *PhibbT, *Pd, *PsiP, *Pi, *Xi, *AvG, *Lbc, *mz, *mR;
-  int* mslot;   // [MCAP] slot, or -1 for a measurement that is not run
-  int2* mseq;   // [MCAP] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
+  int* mslot;   // [res_mcap(N)] slot, or -1 for a measurement that is not run
+  int2* mseq;   // [res_mcap(N)] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
-  int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B, img_len;   // kp: propagates per launch (viekf_batch_step_n)
+  int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B, img_len, mcap;   // kp: propagates per launch (viekf_batch_step_n)
   double* stamps;
 };
 

@@ -288,7 +288,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     for (int u = 0; u < 3; u++) pr0[u] = lds_ld2(S.Praw + 2 * ridv[u]);   // (the first raw columns: buffer 0, published before Bp)
     gain_rows(cur, 44, 50, pr0, S.Kt, crow);
   }
-  int2 sq = S.mseq[min(m, MCAP - 1)];
+  int2 sq = S.mseq[min(m, S.mcap - 1)];
   __syncthreads();  // B1
   RES_STAMP(S, lane == 0, 10);
   int it_ = 0, cnt = 0;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
     const double* kP = (cnt & 1) ? S.Z : S.Kt;   // (double-buffered, see the worker side)
     const double2 kA = crow.kA, wA = crow.wA, kB = crow.kB, wB = crow.wB, kC = crow.kC;   // (own rows: from registers)
-    sq = S.mseq[min(mnext, MCAP - 1)];   // next iteration's table entry (static data): its latency hides behind this update
+    sq = S.mseq[min(mnext, S.mcap - 1)];   // next iteration's table entry (static data): its latency hides behind this update
     const bool gated = cur.gate != 0.0;
     // NaN guard (vi_ekf_meas.cpp:247), decided over every row of K in gain_rows (two service waves: the other one's rows too)
     const bool bad = crow.bad != 0 || (ROLE != 0 && sm[44 + cnt % 3 + (ROLE == 2 ? 0 : 8)] != 0.0);

@@ -345,7 +345,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // columns of measurement m+2 are published in phase m, as they stand after the sweep of measurement m; the service wave
   // applies the one intervening update (m+1) to them itself when it forms the gain rows of m+2 -- so nothing it needs is
   // produced inside its own phase: no hand-shake, no polling, and the publishing sits off every critical path.
-  int2 sq = S.mseq[min(m, MCAP - 1)];
+  int2 sq = S.mseq[min(m, S.mcap - 1)];
   if (m < S.M) {
     apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
     const int s0 = S.mslot[m];
@@ -384,7 +384,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const double fixpending = (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]);   // posted before the barrier by the service wave
     const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
     const double nanw = S.sm[44 + cnt % 3] + S.sm[52 + cnt % 3];   // (the second word: a second service wave's rows)
-    sq = S.mseq[min(mnext, MCAP - 1)];                 // next iteration's table entry (static data)
+    sq = S.mseq[min(mnext, S.mcap - 1)];                 // next iteration's table entry (static data)
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
     const int it = tid;
