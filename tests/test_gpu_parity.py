@@ -73,7 +73,9 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
                                               # N + 14 > 64 lanes: the body lanes on a second service wave (<6,6>, two service waves)
                                               (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0), (2, 63, 2, 2), (2, 59, 1, 2),
                                               # more than 64 features: features 64.. on the body wave's lanes (<7,6>, N <= 72)
-                                              (2, 65, 2, 2), (2, 70, 2, 2), (2, 72, 2, 0), (2, 69, 1, 2)])
+                                              (2, 65, 2, 2), (2, 70, 2, 2), (2, 72, 2, 0), (2, 69, 1, 2),
+                                              # eight blocks per thread (<8,6>, N <= 77: the end of the on-chip family)
+                                              (2, 73, 2, 2), (2, 77, 2, 0)])
 def test_step_parity(B, N, steps, kernel):
     sc = scene.make_scene(B, N, steps, seed=100 + N)
     x_ref, P_ref, res_ref = run_oracle(sc, B, N, steps)
@@ -138,7 +140,7 @@ def test_propagate_only_partial_features_and_qx(N, nfeat):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2)])
+@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2), (76, 2)])
 def test_update_gating_nan_invalid_and_full_update(N, kernel):
     """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update; both kernel
     families (the grouped streaming update has its own gate / skip paths inside a group)"""

@@ -229,7 +229,8 @@ const ResInst kResInst[] = {
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
-    {7, 6, 65, 72, 160, 2},   // ... and features 64.. on the body wave's free lanes; 7 blocks per thread is what the registers hold
+    {7, 6, 65, 72, 160, 2},   // ... and features 64.. on the body wave's free lanes
+    {8, 6, 73, 77, 160, 2},   // 8 blocks per thread: the register file's end (3 scratch operations per update in the worker loop)
     // (<4, 5> -- two 384-thread workgroups per CU, three waves per SIMD at <= 168 VGPRs -- measured 32 % slower: dropped)
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
 };
@@ -407,6 +408,7 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
     case 3: return res_pick<3, 7, 1>(multi, zu);
     case 4: return res_pick<6, 6, 2>(multi, zu);
     case 5: return res_pick<7, 6, 2>(multi, zu);
+    case 6: return res_pick<8, 6, 2>(multi, zu);
   }
   return nullptr;
 }
