@@ -343,7 +343,7 @@ def test_more_measurements_than_one_launch_holds(N, M, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,steps,kernel", [(12, 400, 1), (12, 400, 2), (50, 120, 2)])
+@pytest.mark.parametrize("N,steps,kernel", [(12, 400, 1), (12, 400, 2), (50, 120, 2), (70, 60, 2)])
 def test_long_run_stays_at_parity_and_symmetric(N, steps, kernel):
     """hundreds of steps (20 k updates at N=50..12): the covariance stays symmetric bit for bit and the distance to the oracle
     does not grow beyond the rounding level (the rank-2 update form amplifies any asymmetry of P -- DESIGN section 3 -- which a
