@@ -92,7 +92,13 @@ def test_two_service_waves_full_batch():
 
 def test_two_filters_per_workgroup_sizes_between():
     """B=1024 at feature counts either side of the instance boundaries"""
-    run_full(1024, 26, 2, [0, 300, 1023])
+    run_full(1024, 26, 2, [0, 300, 1023])     # <4,3>
+    run_full(1024, 38, 2, [0, 511, 1023])     # <4,3>, its last size
+    run_full(1024, 39, 2, [0, 256, 1023])     # <5,3>
+    run_full(1024, 43, 2, [0, 255, 1023])     # <5,3>, its last size
+    run_full(1024, 44, 2, [0, 700, 1023])     # <6,3>
+    run_full(1024, 47, 2, [0, 256, 1023])     # <6,3>, its last size
+    run_full(1024, 48, 2, [0, 256, 1023])     # <7,3>, its first
     run_full(1024, 49, 2, [0, 512, 1023])
 
 

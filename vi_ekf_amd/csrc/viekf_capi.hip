@@ -226,6 +226,9 @@ const ResInst kResInst[] = {
                      // so the CU is filled with chains
     {3, 2, 1, 25, 80, 1},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
                      // runs under the other's sweeps
+    {4, 3, 26, 38, 80, 1},   // (a 7-slot instance sweeps 7 slots per update however few the map fills: N = 32 needs 3)
+    {5, 3, 39, 43, 80, 1},
+    {6, 3, 44, 47, 80, 1},
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
@@ -248,7 +251,7 @@ const ResInst kResInst[] = {
 //  * what is left (the triangles of the diagonal tiles, the ragged last tile row when N is not a multiple of 8) is packed
 //    unit by unit into the remaining lanes, best fit first.
 // Returns false when the blocks do not fit RB slots of TW threads.
-bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
+bool build_resmap(int N, int RB, int NWV, std::vector<int>& map, int* used_slots = nullptr) {
   const int TW = 64 * NWV;
   map.assign((size_t)RB * TW, 0);
   if (N > TW || N > 255) return false;
@@ -388,6 +391,23 @@ bool build_resmap(int N, int RB, int NWV, std::vector<int>& map) {
         }
     }
   }
+  // Which SLOT of its wave a group sits in is free as well: every wave's non-empty groups move to its lowest slots (slot 0
+  // keeps the diagonal blocks), and the kernel's per-slot loops stop at the highest slot any wave uses -- a 7-slot instance
+  // that holds N = 32 (3 slots' worth of blocks) then sweeps 3 slots per update, not 7.
+  int used = 1;
+  for (int w = 0; w < NWV; w++) {
+    int dst = (64 * w < N) ? 1 : 0;   // (slot 0 of a wave that holds diagonal blocks stays where it is)
+    for (int sl = dst; sl < RB; sl++) {
+      bool any = false;
+      for (int l = 0; l < 64 && !any; l++) any = (map[(size_t)sl * TW + 64 * w + l] >> 16) != 0;
+      if (!any) continue;
+      if (sl != dst)
+        for (int l = 0; l < 64; l++) std::swap(map[(size_t)sl * TW + 64 * w + l], map[(size_t)dst * TW + 64 * w + l]);
+      dst++;
+    }
+    used = std::max(used, dst);
+  }
+  if (used_slots) *used_slots = used;
   return true;
 }
 
@@ -404,11 +424,14 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
   switch (inst) {
     case 0: return res_pick<2, 1, 1>(multi, zu);
     case 1: return res_pick<3, 2, 1>(multi, zu);
-    case 2: return res_pick<7, 3, 1>(multi, zu);
-    case 3: return res_pick<3, 7, 1>(multi, zu);
-    case 4: return res_pick<6, 6, 2>(multi, zu);
-    case 5: return res_pick<7, 6, 2>(multi, zu);
-    case 6: return res_pick<8, 6, 2>(multi, zu);
+    case 2: return res_pick<4, 3, 1>(multi, zu);
+    case 3: return res_pick<5, 3, 1>(multi, zu);
+    case 4: return res_pick<6, 3, 1>(multi, zu);
+    case 5: return res_pick<7, 3, 1>(multi, zu);
+    case 6: return res_pick<3, 7, 1>(multi, zu);
+    case 7: return res_pick<6, 6, 2>(multi, zu);
+    case 8: return res_pick<7, 6, 2>(multi, zu);
+    case 9: return res_pick<8, 6, 2>(multi, zu);
   }
   return nullptr;
 }
@@ -420,7 +443,8 @@ int setup_resident(viekf_batch* b) {
     const ResInst& r = kResInst[i];
     if (force && atoi(force) != i) continue;
     if (b->N < r.nmin || b->N > r.nmax) continue;
-    const int TR = 0, TC = 0;   // (kernel arguments kept for the launch signature; the ownership map needs neither)
+    int TR = r.RB;              // block slots per thread that the map actually uses (the kernel's per-slot loops stop there)
+    const int TC = 0;           // (kept for the launch signature)
     if (b->N * (b->N + 1) / 2 > r.RB * r.NW * 64 || b->N > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
@@ -432,7 +456,7 @@ int setup_resident(viekf_batch* b) {
       if (r.max_lds_kb <= 40 && b->B <= 2 * cus) continue;   // (four per CU: only when two per CU would leave filters waiting)
     }
     std::vector<int> map;
-    if (!build_resmap(b->N, r.RB, r.NW, map)) continue;
+    if (!build_resmap(b->N, r.RB, r.NW, map, &TR)) continue;
     if (b->d_resmap) { HIP_TRY(hipFree(b->d_resmap)); b->d_resmap = nullptr; }
     HIP_TRY(hipMalloc(&b->d_resmap, sizeof(int) * map.size()));
     HIP_TRY(hipMemcpy(b->d_resmap, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
@@ -872,12 +896,13 @@ int viekf_debug_read_ws(viekf_batch* b, void* out, int count) {
 // diagnostic hook (not part of include/viekf.h; host arithmetic only, no device needed): the fused-step kernel's block
 // ownership map for n_feat features on `nw` worker waves with `rb` slots per thread -> out[rb * 64 * nw] entries
 // I | J << 8 | owned << 16; -1 when the blocks do not fit.  tests/test_resmap_cpu.py checks its invariants.
-int viekf_debug_build_resmap(int n_feat, int rb, int nw, int32_t* out) {
+int viekf_debug_build_resmap(int n_feat, int rb, int nw, int32_t* out) {   // returns the number of slots in use (> 0), -1 on failure
   std::vector<int> map;
+  int used = 0;
   if (n_feat < 1 || rb < 1 || nw < 1 || !out) return -1;
-  if (n_feat * (n_feat + 1) / 2 > rb * nw * 64 || !build_resmap(n_feat, rb, nw, map)) return -1;
+  if (n_feat * (n_feat + 1) / 2 > rb * nw * 64 || !build_resmap(n_feat, rb, nw, map, &used)) return -1;
   for (size_t i = 0; i < map.size(); i++) out[i] = map[i];
-  return 0;
+  return used;
 }
 
 int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem where) {
