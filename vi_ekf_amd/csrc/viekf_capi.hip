@@ -224,12 +224,15 @@ const ResInst kResInst[] = {
     {2, 1, 1, 15, 40, 1},   // the reference's own sizes (NUM_FEATURES 12, params 20 -> here up to 15): ONE worker wave + the service
                      // wave, four 128-thread workgroups per CU (LDS <= 40 KB) -- a small filter's step is its update chain's latency,
                      // so the CU is filled with chains
+    {2, 2, 1, 22, 80, 1},
     {3, 2, 1, 25, 80, 1},   // small filters: 192-thread workgroups, two per CU (LDS <= 80 KB, <= 256 VGPRs): one filter's update chain
                      // runs under the other's sweeps
     {4, 3, 26, 38, 80, 1},   // (a 7-slot instance sweeps 7 slots per update however few the map fills: N = 32 needs 3)
     {5, 3, 39, 43, 80, 1},
     {6, 3, 44, 47, 80, 1},
     {7, 3, 26, 50, 80, 1},   // two 256-thread workgroups per CU at the headline size (7 blocks per thread, LDS <= 80 KB)
+    {1, 7, 1, 29, 160, 1},   // one workgroup per CU (small batches): again the smallest instance that holds the size
+    {2, 7, 30, 41, 160, 1},
     {3, 7, 1, 50, 160, 1},
     {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
     {7, 6, 65, 72, 160, 2},   // ... and features 64.. on the body wave's free lanes
@@ -423,15 +426,18 @@ res_kernel_t res_pick(bool multi, bool zu) {
 res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
   switch (inst) {
     case 0: return res_pick<2, 1, 1>(multi, zu);
-    case 1: return res_pick<3, 2, 1>(multi, zu);
-    case 2: return res_pick<4, 3, 1>(multi, zu);
-    case 3: return res_pick<5, 3, 1>(multi, zu);
-    case 4: return res_pick<6, 3, 1>(multi, zu);
-    case 5: return res_pick<7, 3, 1>(multi, zu);
-    case 6: return res_pick<3, 7, 1>(multi, zu);
-    case 7: return res_pick<6, 6, 2>(multi, zu);
-    case 8: return res_pick<7, 6, 2>(multi, zu);
-    case 9: return res_pick<8, 6, 2>(multi, zu);
+    case 1: return res_pick<2, 2, 1>(multi, zu);
+    case 2: return res_pick<3, 2, 1>(multi, zu);
+    case 3: return res_pick<4, 3, 1>(multi, zu);
+    case 4: return res_pick<5, 3, 1>(multi, zu);
+    case 5: return res_pick<6, 3, 1>(multi, zu);
+    case 6: return res_pick<7, 3, 1>(multi, zu);
+    case 7: return res_pick<1, 7, 1>(multi, zu);
+    case 8: return res_pick<2, 7, 1>(multi, zu);
+    case 9: return res_pick<3, 7, 1>(multi, zu);
+    case 10: return res_pick<6, 6, 2>(multi, zu);
+    case 11: return res_pick<7, 6, 2>(multi, zu);
+    case 12: return res_pick<8, 6, 2>(multi, zu);
   }
   return nullptr;
 }
