@@ -13,7 +13,7 @@ import pytest
 from vi_ekf_amd import capi
 
 # (RB, NW, n_min, n_max) of kResInst in viekf_capi.hip
-INSTANCES = [(2, 1, 1, 15), (2, 2, 1, 22), (3, 2, 1, 25), (1, 7, 1, 29), (2, 7, 30, 41), (4, 3, 26, 38), (5, 3, 39, 43), (6, 3, 44, 47), (7, 3, 26, 50), (3, 7, 1, 50), (6, 6, 51, 64), (7, 6, 65, 72), (8, 6, 73, 77)]
+INSTANCES = [(2, 1, 1, 15), (2, 2, 1, 22), (3, 2, 1, 25), (1, 7, 1, 29), (2, 7, 30, 41), (4, 3, 26, 38), (5, 3, 39, 43), (6, 3, 44, 47), (7, 3, 26, 50), (3, 7, 1, 50), (5, 6, 51, 57), (6, 6, 51, 67), (7, 6, 65, 72), (8, 6, 73, 77)]
 
 
 def build(n, rb, nw):

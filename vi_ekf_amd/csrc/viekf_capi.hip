@@ -234,8 +234,9 @@ const ResInst kResInst[] = {
     {1, 7, 1, 29, 160, 1},   // one workgroup per CU (small batches): again the smallest instance that holds the size
     {2, 7, 30, 41, 160, 1},
     {3, 7, 1, 50, 160, 1},
-    {6, 6, 51, 64, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
-    {7, 6, 65, 72, 160, 2},   // ... and features 64.. on the body wave's free lanes
+    {5, 6, 51, 57, 160, 2},   // more features than one service wave has lanes for (N + 14 > 64): two service waves
+    {6, 6, 51, 67, 160, 2},   // ... and, past 64, features 64.. on the body wave's free lanes
+    {7, 6, 65, 72, 160, 2},
     {8, 6, 73, 77, 160, 2},   // 8 blocks per thread: the register file's end (3 scratch operations per update in the worker loop)
     // (<4, 5> -- two 384-thread workgroups per CU, three waves per SIMD at <= 168 VGPRs -- measured 32 % slower: dropped)
     // (<4, 6> -- 4 blocks per thread on 6 worker waves, the service wave alone on its SIMD -- measured 4 % slower: dropped)
@@ -435,9 +436,10 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
     case 7: return res_pick<1, 7, 1>(multi, zu);
     case 8: return res_pick<2, 7, 1>(multi, zu);
     case 9: return res_pick<3, 7, 1>(multi, zu);
-    case 10: return res_pick<6, 6, 2>(multi, zu);
-    case 11: return res_pick<7, 6, 2>(multi, zu);
-    case 12: return res_pick<8, 6, 2>(multi, zu);
+    case 10: return res_pick<5, 6, 2>(multi, zu);
+    case 11: return res_pick<6, 6, 2>(multi, zu);
+    case 12: return res_pick<7, 6, 2>(multi, zu);
+    case 13: return res_pick<8, 6, 2>(multi, zu);
   }
   return nullptr;
 }
