@@ -119,6 +119,10 @@ int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
 int viekf_batch_sync(viekf_batch *b);
 /* kernel family: 0 = auto, 1 = streaming (P in HBM/L2, any num_features), 2 = resident (P on chip) */
 int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
+/* which kernels a feature-update step of this batch launches, as text (for logs and benchmark records; no reference
+ * counterpart): e.g. "k_step_resident<7,3> ZU: 3 worker waves x 7 blocks + 1 service wave, 2 workgroups per CU".
+ * Writes at most cap bytes including the terminating 0. */
+int viekf_batch_describe(const viekf_batch *b, char *out, int32_t cap);
 
 /* state access.  Replaces get_state()/get_covariance()/get_len_features(), include/vi_ekf.h:271-286,
  * and set_x0 / set_imu_bias, src/vi_ekf/vi_ekf.cpp:157-184.  Any pointer may be NULL (skipped).  A covariance handed to

@@ -86,6 +86,12 @@ class BatchVIEKF:
     def set_kernel(self, family):
         capi.check(capi.lib().viekf_batch_set_kernel(self._h, int(family)))
 
+    def describe(self):
+        """which kernels a step of this batch launches (viekf_batch_describe)"""
+        buf = C.create_string_buffer(256)
+        capi.check(capi.lib().viekf_batch_describe(self._h, buf, 256))
+        return buf.value.decode()
+
     def reset(self):
         capi.check(capi.lib().viekf_batch_reset(self._h))
 

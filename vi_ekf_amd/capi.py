@@ -18,7 +18,7 @@ FLAG_NAN, FLAG_BLOWING_UP, FLAG_NEGATIVE_DEPTH = 1, 2, 4
 # every symbol include/viekf.h declares (tests check the library exports exactly these)
 SYMBOLS = [
     "viekf_abi_version", "viekf_last_error", "viekf_device_count", "viekf_params_default", "viekf_params_load_yaml",
-    "viekf_batch_create", "viekf_batch_destroy", "viekf_batch_reset", "viekf_batch_dims", "viekf_batch_set_stream",
+    "viekf_batch_create", "viekf_batch_destroy", "viekf_batch_reset", "viekf_batch_dims", "viekf_batch_describe", "viekf_batch_set_stream",
     "viekf_batch_sync", "viekf_batch_set_kernel", "viekf_batch_get_state", "viekf_batch_set_state",
     "viekf_batch_get_status", "viekf_batch_propagate", "viekf_batch_init_feature", "viekf_batch_update_feat",
     "viekf_batch_step", "viekf_batch_update", "viekf_batch_keep_features", "viekf_batch_history_resize",
@@ -111,6 +111,7 @@ def lib():
         L.viekf_batch_destroy.argtypes = [_vp]
         L.viekf_batch_reset.argtypes = [_vp]
         L.viekf_batch_dims.argtypes = [_vp] + [C.POINTER(C.c_int32)] * 4
+        L.viekf_batch_describe.argtypes = [_vp, C.c_char_p, C.c_int32]
         L.viekf_batch_set_stream.argtypes = [_vp, _vp]
         L.viekf_batch_sync.argtypes = [_vp]
         L.viekf_batch_set_kernel.argtypes = [_vp, C.c_int32]

@@ -712,6 +712,23 @@ int viekf_batch_dims(const viekf_batch* b, int32_t* batch, int32_t* num_features
   return VIEKF_OK;
 }
 
+int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
+  if (int rc = check_batch(b)) return rc;
+  if (!out || cap < 1) return fail(VIEKF_ERR_INVALID, "describe: no buffer");
+  char buf[256];
+  if (use_resident(b)) {
+    const ResInst& r = kResInst[b->res_inst];
+    snprintf(buf, sizeof buf, "k_step_resident<%d,%d>%s: %d worker waves x %d blocks + %d service wave%s, %s per CU (LDS %zu KB)",
+             r.RB, r.NW, b->res_zu ? " ZU" : "", r.NW, r.RB, r.NS, r.NS > 1 ? "s" : "",
+             r.max_lds_kb <= 40 ? "4 workgroups" : (r.max_lds_kb <= 80 ? "2 workgroups" : "1 workgroup"), b->res_lds / 1024);
+  } else {
+    snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_%s (P in HBM/L2%s)", (stream_mfma_ok() && b->n <= 512) ? "blocked" : "stream",
+             (stream_mfma_ok() && b->n <= 512) ? ", one pass per group of measurements, fp64 MFMA passes" : ", one pass per measurement");
+  }
+  snprintf(out, (size_t)cap, "%s", buf);
+  return VIEKF_OK;
+}
+
 int viekf_batch_get_params(const viekf_batch* b, viekf_params* out) {
   if (!b || !out) return fail(VIEKF_ERR_INVALID, "null argument");
   *out = b->params;
