@@ -2,7 +2,7 @@
 # the (B, N) table of DESIGN.md section 6: one bench.py line per configuration (no CPU baseline, no secondary numbers)
 for cfg in "1 12" "256 25" "256 50" "1024 6" "1024 12" "1024 20" "1024 25" "1024 32" "1024 40" "1024 50" "4096 50" "1024 64" "1024 70" "1024 77" "1024 100" "1024 150"; do
   set -- $cfg
-  steps=50; [ $2 -gt 50 ] && steps=10
+  steps=200; [ $2 -gt 77 ] && steps=10
   python bench.py --batch $1 --feat $2 --steps $steps --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read())
