@@ -112,3 +112,10 @@ def test_four_per_cu_instance_small_filters(N):
 def test_features_on_both_service_waves_full_batch():
     """B=1024, N=70: the <7,6> instance (features 64.. on the body wave's lanes; the measurement list crosses the 64 per launch)"""
     run_full(1024, 70, 2, [0, 255, 256, 1023])
+
+
+@pytest.mark.parametrize("N", [12, 50, 70])
+def test_general_lambda_instances_full_batch(N, monkeypatch):
+    """the same batches on the general-Lambda instances (what a parameter file with lambda_feat[0:2] != 1 selects)"""
+    monkeypatch.setenv("VIEKF_RES_NOZU", "1")
+    run_full(1024, N, 2, [0, 255, 256, 1023])
