@@ -177,3 +177,22 @@ def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
     for k in range(K):
         gs[1].propagate(sc["u"][k], dt[k])
     assert np.array_equal(gs[0].get_covariance(), gs[1].get_covariance())
+
+
+def test_two_batches_of_one_instance_with_different_lds():
+    """a second batch with fewer features on the same kernel instance must not shrink the first one's dynamic-LDS allowance
+    (the MaxDynamicSharedMemorySize attribute is per kernel, not per batch)"""
+    import vi_ekf_amd as v
+    from vi_ekf_amd import scene
+    B = 600
+    sc_a = scene.make_scene(B, 50, 1, seed=5)
+    sc_b = scene.make_scene(B, 48, 1, seed=6)
+    ga = v.BatchVIEKF(B, 50, sc_a["params"])
+    gb = v.BatchVIEKF(B, 48, sc_b["params"])     # same <7,3> instance, smaller LDS image
+    for g, sc, N in ((ga, sc_a, 50), (gb, sc_b, 48)):
+        for i in range(N):
+            g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+    ra = ga.step(sc_a["u"][0], sc_a["dt"], sc_a["z"][0], sc_a["slot"], sc_a["R"])
+    rb = gb.step(sc_b["u"][0], sc_b["dt"], sc_b["z"][0], sc_b["slot"], sc_b["R"])
+    assert (ra == 0).all() and (rb == 0).all()
+    assert np.isfinite(ga.get_state()).all() and np.isfinite(gb.get_state()).all()

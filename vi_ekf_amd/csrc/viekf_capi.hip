@@ -468,14 +468,18 @@ int setup_resident(viekf_batch* b) {
     if (b->d_resmap) { HIP_TRY(hipFree(b->d_resmap)); b->d_resmap = nullptr; }
     HIP_TRY(hipMalloc(&b->d_resmap, sizeof(int) * map.size()));
     HIP_TRY(hipMemcpy(b->d_resmap, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i)),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true)),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, false, true)),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, true, true)),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the attribute belongs to the DEVICE's copy of the kernel and is shared by every batch that runs this instance: it is a
+    //  high-water mark, never lowered -- a second batch with fewer features must not take the first one's LDS away)
+    {
+      static size_t have[64][sizeof(kResInst) / sizeof(kResInst[0])] = {};
+      size_t& hw = have[b->device & 63][i];
+      if (lds > hw) {
+        for (int fl = 0; fl < 4; fl++)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(res_kernel(i, (fl & 1) != 0, (fl & 2) != 0)),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hw = lds;
+      }
+    }
     b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
     break;
   }
