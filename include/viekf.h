@@ -119,6 +119,19 @@ int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
 int viekf_batch_sync(viekf_batch *b);
 /* kernel family: 0 = auto, 1 = streaming (P in HBM/L2, any num_features), 2 = resident (P on chip) */
 int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
+/* Kernel selection knobs for tests and experiments (no reference counterpart; the defaults are what a caller gets and nothing
+ * here changes results beyond rounding):
+ *   VIEKF_TUNE_RES_INSTANCE  index into the resident family's instance table, -1 = automatic (VIEKF_ERR_UNSUPPORTED if that
+ *                            instance does not hold num_features; the automatic choice is then restored)
+ *   VIEKF_TUNE_UNIT_LAMBDA   0 = never the instances specialised for lambda_feat = [1, 1, x]
+ *   VIEKF_TUNE_BLOCK_GROUP   measurements per pass of the grouped wide-P update: 0 = automatic, 16, 24, 32 (used where it fits the LDS)
+ *   VIEKF_TUNE_STREAM_MFMA   0 = the streaming kernels without matrix-core passes (one pass over P per measurement)
+ *   VIEKF_TUNE_TILES         the tile family of the fused step (P as fp64-MFMA accumulator tiles): 0 = never, 1 = automatic,
+ *                            2 = wherever it holds num_features, whatever the batch size */
+typedef enum viekf_tuning {
+  VIEKF_TUNE_RES_INSTANCE = 1, VIEKF_TUNE_UNIT_LAMBDA = 2, VIEKF_TUNE_BLOCK_GROUP = 3, VIEKF_TUNE_STREAM_MFMA = 4, VIEKF_TUNE_TILES = 5
+} viekf_tuning;
+int viekf_batch_set_tuning(viekf_batch *b, int32_t key, int32_t value);
 /* which kernels a feature-update step of this batch launches, as text (for logs and benchmark records; no reference
  * counterpart): e.g. "k_step_resident<7,3> ZU: 3 worker waves x 7 blocks + 1 service wave, 2 workgroups per CU".
  * Writes at most cap bytes including the terminating 0. */
@@ -200,6 +213,9 @@ int viekf_batch_select(viekf_batch *b, int32_t slot);
 int viekf_batch_set_active(viekf_batch *b, const uint8_t *mask, viekf_mem where);
 int viekf_batch_snapshot_filters(viekf_batch *b, const int32_t *slot, viekf_mem where);
 int viekf_batch_restore_filters(viekf_batch *b, const int32_t *slot, viekf_mem where);
+/* (propagate_to advances the WHOLE batch into dst_slot: under a participation mask it returns VIEKF_ERR_INVALID.  Ring slots
+ *  handed to snapshot_filters / restore_filters in DEVICE memory cannot be checked by the host: an out-of-range one is skipped
+ *  and that filter's VIEKF_FLAG_INTERNAL is raised.) */
 int viekf_batch_propagate_to(viekf_batch *b, const double *u, const double *dt, int32_t dst_slot, viekf_mem where);
 
 /* ONE measurement of any model of the reference's table per filter: VIEKF::update with

@@ -53,3 +53,18 @@ def make_twin(N, params, pix=None, depth=None):
         for i in range(len(pix)):
             t.init_feature(pix[i], depth[i] if depth is not None else np.nan)
     return t
+
+
+def apply_kernel(g, kernel):
+    """kernel selection shared by the GPU tests: 0 automatic, 1 streaming family, 2 on-chip families, 3 the tile family whatever the
+    batch size (automatic only beyond one workgroup per CU), 4 on-chip without the tile family"""
+    from vi_ekf_amd import capi
+    if kernel == 3:
+        g.set_tuning(capi.TUNE_TILES, 2)
+        assert "k_step_tiles" in g.describe(), g.describe()
+    elif kernel == 4:
+        g.set_tuning(capi.TUNE_TILES, 0)
+        g.set_kernel(2)
+    elif kernel:
+        g.set_kernel(kernel)
+    return g

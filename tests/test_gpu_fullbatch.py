@@ -38,11 +38,13 @@ def oracle_subset(sc, N, steps, which):
     return np.stack([f.x.copy() for f in fs]), np.stack([f.P.copy() for f in fs]), res
 
 
-def run_full(B, N, steps, which, kernel=0, seed=None):
+def run_full(B, N, steps, which, kernel=0, seed=None, tune=()):
     sc = scene.make_scene(B, N, steps, seed=4000 + N if seed is None else seed)
     g = v.BatchVIEKF(B, N, sc["params"])
     if kernel:
         g.set_kernel(kernel)
+    for key, value in tune:
+        g.set_tuning(key, value)
     for i in range(N):
         ok = g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
         assert (ok == 1).all()
@@ -65,7 +67,7 @@ def run_full(B, N, steps, which, kernel=0, seed=None):
 
 
 def test_headline_batch_every_dispatch_round():
-    """B=1024, N=50 (BASELINE configs[2]): fused <3,7>, one workgroup per CU, four rounds over 256 CUs"""
+    """B=1024, N=50 (BASELINE configs[2]): the headline instance, two workgroups per CU, two rounds over 256 CUs"""
     run_full(1024, 50, 3, [0, 255, 256, 511, 700, 1023])
 
 
@@ -115,7 +117,19 @@ def test_features_on_both_service_waves_full_batch():
 
 
 @pytest.mark.parametrize("N", [12, 50, 70])
-def test_general_lambda_instances_full_batch(N, monkeypatch):
+def test_general_lambda_instances_full_batch(N):
     """the same batches on the general-Lambda instances (what a parameter file with lambda_feat[0:2] != 1 selects)"""
-    monkeypatch.setenv("VIEKF_RES_NOZU", "1")
-    run_full(1024, N, 2, [0, 255, 256, 1023])
+    from vi_ekf_amd import capi
+    g = run_full(1024, N, 2, [0, 255, 256, 1023], tune=[(capi.TUNE_UNIT_LAMBDA, 0)])
+    assert " ZU" not in g.describe()
+
+
+@pytest.mark.parametrize("N,group", [(85, 0), (85, 16), (100, 0), (100, 16), (100, 32), (120, 24)])
+def test_wide_p_group_sizes(N, group):
+    """the grouped update's 24- and 32-measurement instances (chosen on their own for n > 256 where the panel fits: N = 85 ->
+    32, N = 100 -> 24) and forced group sizes, more measurements than one group: x, P (whole, mirrored from the lower
+    triangle) and codes against the oracle, P == P^T bit for bit (those instances had no parity case)"""
+    from vi_ekf_amd import capi
+    g = run_full(64, N, 2, [0, 31, 63], tune=[(capi.TUNE_BLOCK_GROUP, group)] if group else ())
+    d = g.describe()
+    assert "k_update_feat_blocked<512,%d>" % (group if group else (32 if N == 85 else 24)) in d, d

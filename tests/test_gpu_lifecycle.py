@@ -110,7 +110,7 @@ def test_keyframe_reset_matches_oracle(N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0)])
+@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0), (50, 3)])
 def test_propagate_to_ring_slot_equals_in_place(N, kernel):
     """zero-copy history: propagate_to writes the next ring slot and selects it; the old slot keeps the old state"""
     import ctypes as C
@@ -119,8 +119,8 @@ def test_propagate_to_ring_slot_equals_in_place(N, kernel):
     sc = scene.make_scene(B, N, 2, seed=13)
     ga, gb = v.BatchVIEKF(B, N, sc["params"]), v.BatchVIEKF(B, N, sc["params"])
     for g in (ga, gb):
-        if kernel:
-            g.set_kernel(kernel)
+        from tests.helpers import apply_kernel
+        apply_kernel(g, kernel)
         for i in range(N):
             g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
     L = capi.lib()
@@ -143,7 +143,7 @@ def test_propagate_to_ring_slot_equals_in_place(N, kernel):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4), (55, 2, 4), (66, 2, 3)])
+@pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4), (55, 2, 4), (66, 2, 3), (50, 3, 9), (47, 3, 2)])
 def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
     """viekf_batch_step_n: K IMU samples and the frame's updates in one launch (P stays on chip in the fused kernel) --
     bit for bit the K - 1 propagate calls + one step they replace; a forced negative depth makes a propagate's fix_depth
@@ -155,7 +155,8 @@ def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
     gs = []
     for _ in range(2):
         g = v.BatchVIEKF(B, N, sc["params"])
-        g.set_kernel(kernel)
+        from tests.helpers import apply_kernel
+        apply_kernel(g, kernel)
         for i in range(N):
             g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
         x = g.get_state()

@@ -86,6 +86,10 @@ class BatchVIEKF:
     def set_kernel(self, family):
         capi.check(capi.lib().viekf_batch_set_kernel(self._h, int(family)))
 
+    def set_tuning(self, key, value):
+        """kernel selection knobs for tests and experiments (viekf_batch_set_tuning; capi.TUNE_*)"""
+        capi.check(capi.lib().viekf_batch_set_tuning(self._h, int(key), int(value)))
+
     def describe(self):
         """which kernels a step of this batch launches (viekf_batch_describe)"""
         buf = C.create_string_buffer(256)

@@ -13,7 +13,8 @@ from . import _build
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_YAML, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 HOST, DEVICE = 0, 1
 MEAS_SKIPPED, MEAS_SUCCESS, MEAS_GATED, MEAS_NAN, MEAS_INVALID, MEAS_NEW_FEATURE = -1, 0, 1, 2, 3, 4
-FLAG_NAN, FLAG_BLOWING_UP, FLAG_NEGATIVE_DEPTH = 1, 2, 4
+FLAG_NAN, FLAG_BLOWING_UP, FLAG_NEGATIVE_DEPTH, FLAG_INTERNAL = 1, 2, 4, 8
+TUNE_RES_INSTANCE, TUNE_UNIT_LAMBDA, TUNE_BLOCK_GROUP, TUNE_STREAM_MFMA, TUNE_TILES = 1, 2, 3, 4, 5
 
 # every symbol include/viekf.h declares (tests check the library exports exactly these)
 SYMBOLS = [
@@ -29,6 +30,7 @@ SYMBOLS = [
     "viekf_seq_disable_logger", "viekf_batch_step_n", "viekf_batch_get_cov_block", "viekf_seq_get_global_pose",
     "viekf_seq_get_global_cov", "viekf_seq_init_feature", "viekf_batch_set_active", "viekf_batch_snapshot_filters",
     "viekf_batch_restore_filters", "viekf_seq_create_independent", "viekf_seq_propagate_t", "viekf_seq_add_measurement_t",
+    "viekf_batch_set_tuning",
 ]
 
 
@@ -115,6 +117,7 @@ def lib():
         L.viekf_batch_set_stream.argtypes = [_vp, _vp]
         L.viekf_batch_sync.argtypes = [_vp]
         L.viekf_batch_set_kernel.argtypes = [_vp, C.c_int32]
+        L.viekf_batch_set_tuning.argtypes = [_vp, C.c_int32, C.c_int32]
         L.viekf_batch_get_state.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_set_state.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_get_status.argtypes = [_vp, _vp, C.c_int]

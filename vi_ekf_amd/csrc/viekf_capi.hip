@@ -8,12 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/viekf.h"
 #include "viekf_host.hpp"
 #include "viekf_kernels_resident.hpp"
+#include "viekf_kernels_tiles.hpp"
 
 using namespace viekf;
 
@@ -35,6 +37,10 @@ int fail(int code, const std::string& msg) {
 
 constexpr int kThreads = 256;
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a device's copy of a kernel and is shared by every batch (and
+// every host thread) that launches it: the per-device high-water marks below are raised under this lock, never lowered.
+std::mutex g_attr_mutex;
+
 }  // namespace
 
 struct viekf_batch {
@@ -52,7 +58,6 @@ struct viekf_batch {
   int family = 0;       // requested: 0 auto, 1 streaming, 2 resident
   int res_inst = -1;    // resident instance index (-1: N not covered by the resident family)
   bool res_zu = false;  // lambda = 1 on the bearing components (or no partial update): the fused kernel's ZU instances apply
-  int res_TR = 0, res_TC = 0;
   size_t res_lds = 0;
   DevParams dp;
   DevParams* d_dp = nullptr;
@@ -73,6 +78,14 @@ struct viekf_batch {
   bool active_on = false;
   int* d_resmap = nullptr;             // fused-step kernel: block ownership map [RB][TW] of the chosen instance (build_resmap)
   int* d_ringslot = nullptr;           // [B] staging of per-filter ring slots (viekf_batch_snapshot_filters / _restore_filters)
+  // viekf_batch_set_tuning (tests / experiments; the defaults are what a caller gets)
+  int tile_inst = -1;          // tile family (P as MFMA accumulator tiles): index into kTileInst, -1 = not used for this batch
+  size_t tile_lds = 0;
+  int tune_tiles = 1;          // 0: never the tile family
+  int tune_res_inst = -1;      // >= 0: only this index of kResInst is tried
+  int tune_unit_lambda = 1;    // 0: never the unit-Lambda instances
+  int tune_block_group = 0;    // 16 / 24 / 32: group size of the grouped update where its panel fits
+  int tune_stream_mfma = 1;    // 0: the streaming kernels without matrix-core passes
 };
 
 namespace {
@@ -148,23 +161,42 @@ int ensure_full_P(viekf_batch* b, int tolerate = 0) {
   return VIEKF_OK;
 }
 
-bool stream_mfma_ok() {   // VIEKF_STREAM_BLOCKED=0 keeps the kernels without matrix-core passes (experiments)
-  static const bool ok = []() { const char* e = getenv("VIEKF_STREAM_BLOCKED"); return !(e && atoi(e) == 0); }();
-  return ok;
-}
+// (VIEKF_TUNE_STREAM_MFMA = 0 keeps the kernels without matrix-core passes: experiments)
+bool stream_mfma_ok(const viekf_batch* b) { return b->tune_stream_mfma != 0; }
 
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
-  if (int rc = ensure_full_P(b, stream_mfma_ok() ? 1 : 0)) return rc;
+  if (int rc = ensure_full_P(b, stream_mfma_ok(b) ? 1 : 0)) return rc;
   StreamArgs a = make_args(b);
-  if (stream_mfma_ok()) {   // feature/feature part on the fp64 matrix cores: reads the lower triangle, writes all of P
+  if (stream_mfma_ok(b)) {   // feature/feature part on the fp64 matrix cores: reads the lower triangle, writes all of P
     hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2 + 8 * 16 * 17),
                        b->stream, a, d_u, d_dt);
-    b->upper_stale = 0;
+    // ... of the filters that take part: under a participation mask the others keep whatever staleness they had
+    if (!b->active_on) b->upper_stale = 0;
   } else
     hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
                        d_dt);
   HIP_TRY(hipGetLastError());
   return VIEKF_OK;
+}
+
+// Group size of the grouped update (k_update_feat_blocked): the largest of 32 / 24 / 16 whose panel fits the LDS (fewer passes
+// over P for the narrower filters); 0 = the grouped kernel does not apply (then one pass per measurement).
+// (measured: at N = 64 groups of 32 are SLOWER than 16 -- 1.96 vs 1.83 ms per step, the sequential panel phase grows with the
+//  group -- while N = 100 gains 4 % from 24: the wider groups only where the passes dominate)
+int blocked_group(const viekf_batch* b, size_t* lds_bytes) {
+  if (!stream_mfma_ok(b) || b->n > 512) return 0;
+  auto fits = [&](int cand, size_t* bytes) {
+    const BlkLds BL(b->N, b->n, b->nxs, cand);
+    *bytes = sizeof(double) * (size_t)BL.total;
+    return *bytes + 1024 <= 160 * 1024;   // (+ the kernel's small static LDS)
+  };
+  size_t bytes = 0;
+  if (b->tune_block_group && fits(b->tune_block_group, &bytes)) { if (lds_bytes) *lds_bytes = bytes; return b->tune_block_group; }
+  for (int cand : {32, 24, 16}) {
+    if (cand > 16 && b->n <= 256) continue;
+    if (fits(cand, &bytes)) { if (lds_bytes) *lds_bytes = bytes; return cand; }
+  }
+  return 0;
 }
 
 int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, const double* d_R, int r_mode,
@@ -174,37 +206,20 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
-  // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass);
-  // VIEKF_STREAM_BLOCKED=0 keeps the one-pass-per-measurement kernel (experiments)
-  const bool blocked_ok = stream_mfma_ok();
-  // group size: the largest of 32 / 24 / 16 whose panel fits the LDS (fewer passes over P for the narrower filters)
-  int bg = 0;
+  // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass)
   size_t blds = 0;
-  // (measured: at N = 64 groups of 32 are SLOWER than 16 -- 1.96 vs 1.83 ms per step, the sequential panel phase grows with
-  //  the group -- while N = 100 gains 4 % from 24: the wider groups only where the passes dominate)
-  for (int cand : {32, 24, 16}) {
-    if (cand > 16 && b->n <= 256) continue;
-    const BlkLds BL(b->N, b->n, b->nxs, cand);
-    blds = sizeof(double) * (size_t)BL.total;
-    if (blds + 1024 <= 160 * 1024) { bg = cand; break; }   // (+ the kernel's small static LDS)
-  }
-  if (const char* e = getenv("VIEKF_BLOCK_GROUP")) {   // (experiments)
-    const int want = atoi(e);
-    if (want == 16 || want == 24 || want == 32) {
-      const BlkLds BL(b->N, b->n, b->nxs, want);
-      if (sizeof(double) * (size_t)BL.total + 1024 <= 160 * 1024) { bg = want; blds = sizeof(double) * (size_t)BL.total; }
-    }
-  }
-  if (blocked_ok && M >= 2 && b->n <= 512 && bg > 0) {
+  const int bg = blocked_group(b, &blds);
+  if (M >= 2 && bg > 0) {
     typedef void (*blk_kernel_t)(StreamArgs, const double*, const int*, int, const double*, long, long, int*);
     const blk_kernel_t kern = bg == 32 ? k_update_feat_blocked<512, 32> : (bg == 24 ? k_update_feat_blocked<512, 24> : k_update_feat_blocked<512, 16>);
-    // (a function attribute belongs to the DEVICE's copy of the kernel: one high-water mark per device and instance, so that a
-    //  process driving several GPUs through hipSetDevice raises the limit on each of them)
-    static size_t attr_bytes[64][3] = {};
-    size_t& have = attr_bytes[b->device & 63][bg == 32 ? 2 : (bg == 24 ? 1 : 0)];
-    if (blds > have) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
-      have = blds;
+    {
+      std::lock_guard<std::mutex> lk(g_attr_mutex);
+      static size_t attr_bytes[64][3] = {};
+      size_t& have = attr_bytes[b->device & 63][bg == 32 ? 2 : (bg == 24 ? 1 : 0)];
+      if (blds > have) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+        have = blds;
+      }
     }
     hipLaunchKernelGGL(kern, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb, rsm, d_res);
     b->upper_stale = 1;
@@ -415,7 +430,7 @@ bool build_resmap(int N, int RB, int NWV, std::vector<int>& map, int* used_slots
   return true;
 }
 
-typedef void (*res_kernel_t)(StreamArgs, int, int, int, const double*, const double*, const double*, const int*, int, int,
+typedef void (*res_kernel_t)(StreamArgs, int, const double*, const double*, const double*, const int*, int, int,
                              const double*, long, long, int*);
 // multi: several propagates per launch (viekf_batch_step_n); zu: the unit-Lambda instances (both flavours: step_n must stay
 // bit for bit what K propagates and a step give)
@@ -444,15 +459,58 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
   return nullptr;
 }
 
+// Tile family instances <NT, NW>: NT tiles per side (an instance runs the feature counts with 1 + ceil(N / 5) == NT: its
+// tile -> wave map is compile-time), NW worker waves + 1 service wave (N + 14 <= 64 lanes).
+struct TileInst { int NT, NW, max_lds_kb; };
+const TileInst kTileInst[] = {
+    {11, 3, 80},   // N = 46 .. 50: two 256-thread workgroups per CU (B > #CUs): the headline instance
+};
+
+res_kernel_t tile_kernel(int inst, bool multi) {
+  switch (inst) {
+    case 0: return multi ? k_step_tiles<11, 3, true> : k_step_tiles<11, 3, false>;
+  }
+  return nullptr;
+}
+
+int setup_tiles(viekf_batch* b) {
+  b->tile_inst = -1;
+  if (!b->tune_tiles || b->N + 14 > 64 || b->N < 1) return VIEKF_OK;
+  const int NT = 1 + (b->N + 4) / 5;
+  for (int i = 0; i < (int)(sizeof(kTileInst) / sizeof(kTileInst[0])); i++) {
+    const TileInst& r = kTileInst[i];
+    if (r.NT != NT || 16 * NT > 64 * r.NW) continue;   // (one worker thread per tile-space row brings the next column pair up to date)
+    const TileLds L(b->N, b->n, b->nxs);
+    const size_t lds = sizeof(double) * (size_t)L.total;
+    if (lds > (size_t)r.max_lds_kb * 1024) continue;
+    if (r.max_lds_kb <= 80 && b->tune_tiles != 2) {   // two workgroups per CU only pay when the batch fills the CUs more than once
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
+      if (b->B <= cus) continue;
+    }
+    {
+      std::lock_guard<std::mutex> lk(g_attr_mutex);
+      static size_t have[64][sizeof(kTileInst) / sizeof(kTileInst[0])] = {};
+      size_t& hw = have[b->device & 63][i];
+      if (lds > hw) {
+        for (int fl = 0; fl < 2; fl++)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel(i, fl != 0)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hw = lds;
+      }
+    }
+    b->tile_inst = i; b->tile_lds = lds;
+    break;
+  }
+  return VIEKF_OK;
+}
+
 int setup_resident(viekf_batch* b) {
   b->res_inst = -1;
-  const char* force = getenv("VIEKF_RES_INST");   // (experiments: pick an instance by index)
+  const bool force = b->tune_res_inst >= 0;   // (VIEKF_TUNE_RES_INSTANCE: pick an instance by index)
   for (int i = 0; i < (int)(sizeof(kResInst) / sizeof(kResInst[0])); i++) {
     const ResInst& r = kResInst[i];
-    if (force && atoi(force) != i) continue;
+    if (force && b->tune_res_inst != i) continue;
     if (b->N < r.nmin || b->N > r.nmax) continue;
-    int TR = r.RB;              // block slots per thread that the map actually uses (the kernel's per-slot loops stop there)
-    const int TC = 0;           // (kept for the launch signature)
     if (b->N * (b->N + 1) / 2 > r.RB * r.NW * 64 || b->N > r.NW * 64) continue;
     const ResLds L(b->N, b->n, b->nxs);
     const size_t lds = sizeof(double) * (size_t)L.total;
@@ -464,13 +522,14 @@ int setup_resident(viekf_batch* b) {
       if (r.max_lds_kb <= 40 && b->B <= 2 * cus) continue;   // (four per CU: only when two per CU would leave filters waiting)
     }
     std::vector<int> map;
-    if (!build_resmap(b->N, r.RB, r.NW, map, &TR)) continue;
+    if (!build_resmap(b->N, r.RB, r.NW, map)) continue;
     if (b->d_resmap) { HIP_TRY(hipFree(b->d_resmap)); b->d_resmap = nullptr; }
     HIP_TRY(hipMalloc(&b->d_resmap, sizeof(int) * map.size()));
     HIP_TRY(hipMemcpy(b->d_resmap, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
     // (the attribute belongs to the DEVICE's copy of the kernel and is shared by every batch that runs this instance: it is a
     //  high-water mark, never lowered -- a second batch with fewer features must not take the first one's LDS away)
     {
+      std::lock_guard<std::mutex> lk(g_attr_mutex);
       static size_t have[64][sizeof(kResInst) / sizeof(kResInst[0])] = {};
       size_t& hw = have[b->device & 63][i];
       if (lds > hw) {
@@ -480,20 +539,26 @@ int setup_resident(viekf_batch* b) {
         hw = lds;
       }
     }
-    b->res_inst = i; b->res_TR = TR; b->res_TC = TC; b->res_lds = lds;
+    b->res_inst = i; b->res_lds = lds;
     break;
   }
   return VIEKF_OK;
 }
 
-// VIEKF_DEBUG_ABLATE: timing-only switches (results become wrong): 1 skip sweeps, 2 skip state correction, 4 skip gain rows
+// Timing-only ablation (results become wrong) exists in a -DVIEKF_ABLATE diagnostic build only (tools/build_variant.sh): the
+// bits 1 skip sweeps, 2 skip state correction, 4 skip the column extraction come from VIEKF_DEBUG_ABLATE there.  The product
+// library has no such switch.
+#ifdef VIEKF_ABLATE
 int dbg_bits() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("VIEKF_DEBUG_ABLATE"); v = e ? atoi(e) : 0; }
+  static const int v = []() { const char* e = getenv("VIEKF_DEBUG_ABLATE"); return e ? atoi(e) : 0; }();
   return v;
 }
+#else
+constexpr int dbg_bits() { return 0; }
+#endif
 
-bool use_resident(const viekf_batch* b) { return b->res_inst >= 0 && b->family != 1; }
+bool use_tiles(const viekf_batch* b) { return b->tile_inst >= 0 && b->family != 1; }
+bool use_resident(const viekf_batch* b) { return (b->res_inst >= 0 || b->tile_inst >= 0) && b->family != 1; }
 
 // one launch handles at most res_mcap(N) measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
@@ -505,13 +570,16 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
-  const ResInst& r = kResInst[b->res_inst];
+  const bool tiles = use_tiles(b);
+  const res_kernel_t kern = tiles ? tile_kernel(b->tile_inst, KP > 1) : res_kernel(b->res_inst, KP > 1, b->res_zu);
+  const int threads = tiles ? (kTileInst[b->tile_inst].NW + 1) * 64 : (kResInst[b->res_inst].NW + kResInst[b->res_inst].NS) * 64;
+  const size_t lds = tiles ? b->tile_lds : b->res_lds;
   int m0 = 0;
   do {
     const int cap = res_mcap(b->N);
     const int mc = (M - m0 < cap) ? (M - m0) : cap;
-    hipLaunchKernelGGL(res_kernel(b->res_inst, KP > 1, b->res_zu), dim3(b->B), dim3((r.NW + r.NS) * 64), b->res_lds, b->stream, a, b->res_TR,
-                       b->res_TC, ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
+    hipLaunchKernelGGL(kern, dim3(b->B), dim3(threads), lds, b->stream, a,
+                       ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
     HIP_TRY(hipGetLastError());
@@ -673,8 +741,8 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   up(b->d_x0, p->x0, 17);
   if (hipMemcpy(b->d_dp, &b->dp, sizeof(DevParams), hipMemcpyHostToDevice) != hipSuccess) rc = VIEKF_ERR_HIP;
   b->res_zu = !p->use_partial_update || (p->lambda_feat[0] == 1.0 && p->lambda_feat[1] == 1.0);
-  if (getenv("VIEKF_RES_NOZU")) b->res_zu = false;   // (experiments / tests: the general-Lambda instances)
   if (rc == VIEKF_OK) rc = setup_resident(b);
+  if (rc == VIEKF_OK) rc = setup_tiles(b);
   if (rc == VIEKF_OK) rc = viekf_batch_reset(b);
   if (rc != VIEKF_OK) {
     viekf_batch_destroy(b);
@@ -720,14 +788,22 @@ int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
   if (int rc = check_batch(b)) return rc;
   if (!out || cap < 1) return fail(VIEKF_ERR_INVALID, "describe: no buffer");
   char buf[256];
-  if (use_resident(b)) {
+  if (use_tiles(b)) {
+    const TileInst& r = kTileInst[b->tile_inst];
+    snprintf(buf, sizeof buf, "k_step_tiles<%d,%d>: P as %d 16x16 fp64-MFMA accumulator tiles on %d worker waves + 1 service wave, %s per CU (LDS %zu KB)",
+             r.NT, r.NW, r.NT * (r.NT + 1) / 2, r.NW, r.max_lds_kb <= 80 ? "2 workgroups" : "1 workgroup", b->tile_lds / 1024);
+  } else if (use_resident(b)) {
     const ResInst& r = kResInst[b->res_inst];
     snprintf(buf, sizeof buf, "k_step_resident<%d,%d>%s: %d worker waves x %d blocks + %d service wave%s, %s per CU (LDS %zu KB)",
              r.RB, r.NW, b->res_zu ? " ZU" : "", r.NW, r.RB, r.NS, r.NS > 1 ? "s" : "",
              r.max_lds_kb <= 40 ? "4 workgroups" : (r.max_lds_kb <= 80 ? "2 workgroups" : "1 workgroup"), b->res_lds / 1024);
   } else {
-    snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_%s (P in HBM/L2%s)", (stream_mfma_ok() && b->n <= 512) ? "blocked" : "stream",
-             (stream_mfma_ok() && b->n <= 512) ? ", one pass per group of measurements, fp64 MFMA passes" : ", one pass per measurement");
+    const int bg = blocked_group(b, nullptr);
+    if (bg > 0)
+      snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_blocked<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
+               "passes; a single measurement: k_update_feat_stream)", bg, bg);
+    else
+      snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_stream (P in HBM/L2, one pass per measurement)");
   }
   snprintf(out, (size_t)cap, "%s", buf);
   return VIEKF_OK;
@@ -760,9 +836,47 @@ int viekf_batch_sync(viekf_batch* b) {
 int viekf_batch_set_kernel(viekf_batch* b, int32_t family) {
   if (int rc = check_batch(b)) return rc;
   if (family < 0 || family > 2) return fail(VIEKF_ERR_INVALID, "kernel family must be 0, 1 or 2");
-  if (family == 2 && b->res_inst < 0)
-    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (1..64)");
+  if (family == 2 && b->res_inst < 0 && b->tile_inst < 0)
+    return fail(VIEKF_ERR_UNSUPPORTED, "resident kernel family does not cover this num_features (1..77)");
   b->family = family;
+  return VIEKF_OK;
+}
+
+int viekf_batch_set_tuning(viekf_batch* b, int32_t key, int32_t value) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  switch (key) {
+    case VIEKF_TUNE_RES_INSTANCE:
+      if (value < -1 || value >= (int)(sizeof(kResInst) / sizeof(kResInst[0]))) return fail(VIEKF_ERR_INVALID, "no such resident instance");
+      b->tune_res_inst = value;
+      break;
+    case VIEKF_TUNE_UNIT_LAMBDA:
+      b->tune_unit_lambda = value != 0;
+      b->res_zu = b->tune_unit_lambda && (!b->params.use_partial_update || (b->params.lambda_feat[0] == 1.0 && b->params.lambda_feat[1] == 1.0));
+      return VIEKF_OK;
+    case VIEKF_TUNE_BLOCK_GROUP:
+      if (value != 0 && value != 16 && value != 24 && value != 32) return fail(VIEKF_ERR_INVALID, "group size must be 0 (auto), 16, 24 or 32");
+      b->tune_block_group = value;
+      return VIEKF_OK;
+    case VIEKF_TUNE_TILES:
+      if (value < 0 || value > 2) return fail(VIEKF_ERR_INVALID, "tile family: 0 off, 1 automatic, 2 whatever the batch size");
+      b->tune_tiles = value;
+      HIP_TRY(hipStreamSynchronize(b->stream));
+      return setup_tiles(b);
+    case VIEKF_TUNE_STREAM_MFMA:
+      b->tune_stream_mfma = value != 0;
+      if (!b->tune_stream_mfma) { if (int rc = ensure_full_P(b)) return rc; }   // (the plain kernels read all of P)
+      return VIEKF_OK;
+    default:
+      return fail(VIEKF_ERR_INVALID, "unknown tuning key");
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));   // (the ownership map of the old instance may still be in use)
+  if (int rc = setup_resident(b)) return rc;
+  if (b->tune_res_inst >= 0 && b->res_inst < 0) {
+    b->tune_res_inst = -1;
+    if (int rc = setup_resident(b)) return rc;
+    return fail(VIEKF_ERR_UNSUPPORTED, "this resident instance does not hold the batch's num_features");
+  }
   return VIEKF_OK;
 }
 
@@ -1097,8 +1211,8 @@ static int history_copy(viekf_batch* b, int32_t slot, bool save) {
   if (int rc = check_batch(b)) return rc;
   // (a covariance is copied as it stands, stale upper triangle included; what comes back from the ring is taken to be as stale
   //  as anything this batch ever produced)
-  if (!save) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;
   if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
+  if (!save) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;
   HIP_TRY(hipSetDevice(b->device));
   const size_t nl = sizeof(int) * (size_t)b->B;
   char* hl = reinterpret_cast<char*>(b->h_len) + nl * slot;
@@ -1139,10 +1253,11 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, in
   if (b->hist_depth <= 0) return fail(VIEKF_ERR_INVALID, "no history ring (viekf_batch_history_resize first)");
   if (b->live_slot >= 0) return fail(VIEKF_ERR_INVALID, "per-filter ring copies need the live state in the batch's own buffers (viekf_batch_select(-1))");
   HIP_TRY(hipSetDevice(b->device));
-  if (!to_ring) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
+  // (host slots are validated here; device slots by the kernel, which skips an out-of-range one and raises VIEKF_FLAG_INTERNAL)
   if (where == VIEKF_HOST)
     for (int i = 0; i < b->B; i++)
       if (slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
+  if (!to_ring) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   const int* d_slot = slot;
   if (where == VIEKF_HOST) {
     if (!b->d_ringslot) HIP_TRY(hipMalloc(&b->d_ringslot, sizeof(int) * (size_t)b->B));
@@ -1150,7 +1265,7 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, in
     d_slot = b->d_ringslot;
   }
   StreamArgs a = make_args(b);
-  hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->h_x, b->h_P, d_slot, to_ring);
+  hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->h_x, b->h_P, d_slot, to_ring, b->hist_depth);
   HIP_TRY(hipGetLastError());
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
@@ -1160,8 +1275,8 @@ int viekf_batch_restore_filters(viekf_batch* b, const int32_t* slot, viekf_mem w
 
 int viekf_batch_select(viekf_batch* b, int32_t slot) {
   if (int rc = check_batch(b)) return rc;
-  b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   if (slot < -1 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+  b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
   b->live_slot = slot;
   b->d_x = slot < 0 ? b->home_x : slot_x(b, slot);
@@ -1174,6 +1289,9 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   if (!u || !dt) return fail(VIEKF_ERR_INVALID, "u and dt must not be null");
   if (dst_slot < 0 || dst_slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
   if (dst_slot == b->live_slot) return viekf_batch_propagate(b, u, dt, where);
+  // (a filter outside a participation mask would have nothing written into the destination slot, which then becomes the live
+  //  state: the zero-copy ring is for filters that advance together)
+  if (b->active_on) return fail(VIEKF_ERR_INVALID, "viekf_batch_propagate_to under a participation mask (viekf_batch_set_active(NULL) first)");
   HIP_TRY(hipSetDevice(b->device));
   const double *d_u = nullptr, *d_dt = nullptr;
   if (where == VIEKF_HOST)

@@ -81,7 +81,7 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
 // ZU: lambda = 1 on the bearing components of every feature (the reference's parameter files: lambda_feat = [1, 1, x]; checked
 // by the host), which makes Lambda = 1 for every element of a feature/feature block except (rho, rho).
 template <int RB, int NW, bool MP = false, int NS = 1, bool ZU = false>
-__global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int TR, int TD, int do_prop,
+__global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resident(StreamArgs a, int do_prop,
                                                                 const double* __restrict__ u_all,
                                                                 const double* __restrict__ dt_all,
                                                                 const double* __restrict__ z_all,

@@ -1155,11 +1155,15 @@ __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
 // to_ring != 0: live -> ring.  Filters on independent clocks advance and rewind their rings separately (viekf_seq, independent
 // mode); the feature counts are not part of a slot, as in the reference's ring (include/vi_ekf.h:156-160).
 __global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restrict__ ring_x, double* __restrict__ ring_P,
-                                                   const int* __restrict__ slot, int to_ring) {
+                                                   const int* __restrict__ slot, int to_ring, int depth) {
   const int b = blockIdx.x;
   if (b >= a.B) return;
   const int sl = slot[b];
   if (sl < 0) return;
+  if (sl >= depth) {   // (a device-resident slot list cannot be validated by the host: nothing is copied, the filter is flagged)
+    if (threadIdx.x == 0) atomicOr(&a.flags[b], FLAG_INTERNAL);
+    return;
+  }
   const long nP = (long)a.n * a.ld;
   double* lx = a.x + (long)b * a.nxs;
   double* lP = a.P + (long)b * nP;

@@ -116,6 +116,13 @@ __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-unif
 #define RES_STAMP(S_, who, idx) do {} while (0)
 #endif
 
+// Timing-only ablation bits (results become wrong) exist in a -DVIEKF_ABLATE diagnostic build only; the product build has none.
+#ifdef VIEKF_ABLATE
+#define RES_ABLATE(S_, bit) (((S_).dbg & (bit)) != 0)
+#else
+#define RES_ABLATE(S_, bit) false
+#endif
+
 typedef __attribute__((address_space(3))) volatile int lds_vint_t;
 
 struct ResShared {  // resolved LDS pointers + launch constants shared by both roles

@@ -304,7 +304,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const bool bad = crow.bad != 0 || (ROLE != 0 && sm[44 + cnt % 3 + (ROLE == 2 ? 0 : 8)] != 0.0);
     const double r0 = cur.r0, r1 = cur.r1;
     double2 prn[3] = {};
-    if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !(S.dbg & 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
+    if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !RES_ABLATE(S, 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
     const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
-    const bool corr = !gated && !bad && !(S.dbg & 2);
+    const bool corr = !gated && !bad && !RES_ABLATE(S, 2);
     // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
     // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
     if (corr) {
@@ -373,11 +373,6 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     if (PRIMARY && result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
     if (slot_next >= 0) gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), prn, (cnt & 1) ? S.Kt : S.Z, nrow);
-    {   // this wave's share of the body-column sweep of measurement m (few worker waves only), after its chain
-      constexpr int NWV = T / 64 - 1;
-      const int ns = res_service_items<NWV>(N);
-      if (ns > 0) res_body_items(S, kP, !gated && !bad && !(S.dbg & 1), lane, 64, 8 * N - ns, 8 * N, sq.y, S.Praw + (cnt & 1) * 2 * n);
-    }
     cur = nxt;
     crow = nrow;
     par ^= 1;

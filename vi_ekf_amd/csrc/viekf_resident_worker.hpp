@@ -100,13 +100,8 @@ __device__ __forceinline__ void res_body_items(const ResShared& S, const double*
     }
   }
 }
-// how many of the 8 N body-column items of an update the service wave sweeps (after its chain), by worker-wave count.
-// With the blocks dealt round-robin along wrapped diagonals (r02a) the three worker waves of <7,3> were the longer side and 5 N
-// items on the service wave paid 9 %; with the tile map (build_resmap) the service chain is the longest wave of an update again
-// and every share > 0 measured slower (N = 50, B = 1024: 0 / N / 2 N items -> 0.348 / 0.347 / 0.353 ms per step).
-template <int NWV>
-__device__ __forceinline__ int res_service_items(int N) { return 0; }
-
+// (The service wave takes no share of the body-column items: with the tile map its chain is the longest wave of an update and
+//  every share > 0 measured slower -- N = 50, B = 1024: 0 / N / 2 N items -> 0.348 / 0.347 / 0.353 ms per step.)
 template <int RB, int TW, bool MP, int T = TW + 64, bool ZU = false>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
@@ -392,7 +387,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     //      few blocks per thread; two at a time with many, where holding every block's rows would not fit the register file
     constexpr int GB = (RB <= 4) ? RB : 2;
     const bool gated = gflag != 0.0;
-    const bool run = !gated && nanw == 0.0 && !(S.dbg & 1);   // not gated, no NaN guard
+    const bool run = !gated && nanw == 0.0 && !RES_ABLATE(S, 1);   // not gated, no NaN guard
     bool fixed = false;
 #pragma unroll
     for (int g0 = 0; g0 < RB; g0 += GB) {
@@ -431,7 +426,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     // ---- (2) the raw feature rows of the measurement after next (a fix_depth edit touches P(rho,rho) only, never these
     //      columns), into the buffer the service wave is not reading in this phase
     double* rawdst = S.Praw + (cnt & 1) * 2 * n;
-    if (sq.y >= 0 && !(S.dbg & 4)) extract_cols(sq.y, rawdst);
+    if (sq.y >= 0 && !RES_ABLATE(S, 4)) extract_cols(sq.y, rawdst);
     __builtin_amdgcn_s_setprio(0);
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
@@ -439,7 +434,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     // ---- (3) body columns, in LDS (res_body_items).  Wave 0 takes the last places in the item order, so that the incomplete
     //      final round falls to the other waves: it is the longest of the workers whenever its SIMD-mate is the other workgroup's
     //      service wave.
-    res_body_items(S, kP, run, (it >= 64) ? it - 64 : it + TW - 64, TW, 0, 8 * N - res_service_items<NWV>(N), sq.y, rawdst);
+    res_body_items(S, kP, run, (it >= 64) ? it - 64 : it + TW - 64, TW, 0, 8 * N, sq.y, rawdst);
     if (run) {   // body block: 2 adjacent elements per task, 128 tasks on the top 128 threads (a single worker wave: two tasks
                  // per thread).  Element (r, c) and its mirror (c, r) are owned by different tasks; both form
                  // p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own (equal) copies, so the block stays exactly

@@ -1,0 +1,365 @@
+// viekf_tiles_worker.hpp -- tile family: the worker waves (16 x 16 tiles of P in matrix-core accumulator layout: load, propagate,
+// rank-4 MFMA sweeps, column extraction, store).  Overview: viekf_tiles_common.hpp.
+#pragma once
+#include <utility>
+
+#include "viekf_tiles_common.hpp"
+
+namespace viekf {
+
+// Tile -> (wave, slot), fixed at COMPILE time: tile (TI, TJ), TI >= TJ, belongs to wave (TI + TJ) mod NW -- the NT tiles that
+// hold one feature's rows and columns (tile row T and tile column T) then spread evenly over the waves, and every update
+// extracts the next column pair from all of them; a wave's slots are ordered by (TI, TJ).  Each worker wave runs its own
+// instantiation of the code below (tile_worker<.., W>), in which every tile index is a constant: addresses become immediates,
+// the per-tile tests scalar compares against constants (with the map as run-time data -- the first version of this file -- the
+// same loops compiled to 9,000 instructions per update and 1,500 spilled registers).
+template <int NT, int NW>
+struct TileMap {
+  static constexpr int count(int w) {
+    int c = 0;
+    for (int TI = 0; TI < NT; TI++)
+      for (int TJ = 0; TJ <= TI; TJ++)
+        if ((TI + TJ) % NW == w) c++;
+    return c;
+  }
+  static constexpr int max_count() {
+    int m = 0;
+    for (int w = 0; w < NW; w++) m = count(w) > m ? count(w) : m;
+    return m;
+  }
+  static constexpr int find(int w, int s, bool want_i) {   // slot s of wave w -> TI or TJ (-1: the wave has fewer tiles)
+    int c = 0;
+    for (int TI = 0; TI < NT; TI++)
+      for (int TJ = 0; TJ <= TI; TJ++)
+        if ((TI + TJ) % NW == w) {
+          if (c == s) return want_i ? TI : TJ;
+          c++;
+        }
+    return -1;
+  }
+  static constexpr int ti(int w, int s) { return find(w, s, true); }
+  static constexpr int tj(int w, int s) { return find(w, s, false); }
+};
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int CNT, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, CNT>{}, f); }
+
+// MFMA operand conventions (v_mfma_f64_16x16x4_f64; MI355X_MICROARCH.md "Matrix cores"):  D = A B + C  with, for lane l,
+//   A: one double = A[i = l & 15][k = l >> 4]      B: one double = B[k = l >> 4][j = l & 15]
+//   C / D: four doubles, register r = D[i = (l >> 4) + 4 r][j = l & 15]
+// A tile register X[r] holds P[prow(TI, l & 15)][prow(TJ, (l >> 4) + 4 r)]: D's column index j runs along the ROWS of P inside
+// tile row TI, D's row index i along the columns inside tile column TJ.  So the A operand carries the TJ-side factor and the
+// B operand the TI-side factor, both indexed by l & 15, component k = l >> 4.
+template <int NT, int NW, int W, bool MP>
+__device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShared& S, int tid) {
+  typedef TileMap<NT, NW> Map;
+  constexpr int TW = NW * 64, TPW = Map::max_count(), CNT = Map::count(W);
+  const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len, NQ = S.NQ;
+  const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const DevParams& prm = *a.dp;
+  double* P = a.P + (long)S.b * n * ld;
+  double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns, in LDS during load and propagate
+  double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
+  (void)TPW;
+
+  // ---------------- load: feature/feature tiles from the lower triangle of P (a diagonal tile mirrors it), body columns -> LDS
+  v4f64 X[CNT];
+  static_for<CNT>([&](auto sc) {
+    constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+    v4f64 x = {0.0, 0.0, 0.0, 0.0};
+    if (TJ >= 1) {
+      const int rb = tile_prow(TI, l15, nf);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ca = tile_prow(TJ, lg + 4 * r, nf);
+        if (rb >= 0 && ca >= 0) x[r] = (TI == TJ) ? P[max(rb, ca) + (long)min(rb, ca) * ld] : P[rb + (long)ca * ld];
+      }
+    }
+    X[s] = x;
+  });
+  for (int e = tid; e < nf * 16; e += TW) {   // body columns -> LDS (coalesced along rows)
+    const int k = e / nf, row = e - k * nf;
+    Pbc[row * 16 + k] = P[(16 + row) + (long)k * ld];
+  }
+  for (int e = tid; e < 256; e += TW) {       // body block, both copies of a pair from the lower triangle
+    const int r = e & 15, c = e >> 4;
+    Pbb[r * 16 + c] = P[max(r, c) + (long)min(r, c) * ld];
+  }
+  int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  const double p0rr = uniform_f64(prm.P0_feat[2]);
+  // applies the pending fix_depth covariance edits of mailbox `mb` (vi_ekf_helper.cpp:141-151: P(rho,rho) += err^2 / = P0) to the
+  // diagonal tiles this wave holds: element a = b = 3 j + 2 of tile (T, T) is feature 5 (T - 1) + j
+  auto apply_fixes = [&](int mb, double pending) {
+    if (pending == 0.0) return;   // nothing posted (the common case)
+    static_for<CNT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+      if (TI != TJ || TI == 0) return;
+      const int j = l15 / 3, f = 5 * (TI - 1) + j;
+      const bool mine = (l15 == 3 * j + 2) && (lg == (l15 & 3)) && f < len;
+      if (mine) {
+        const double ad = S.fixadd[mb * N + f], st = S.fixset[mb * N + f];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if ((l15 >> 2) == r) {
+            if (ad != 0.0) X[s][r] += ad;
+            if (st != 0.0) X[s][r] = p0rr;
+          }
+        if (ad != 0.0) S.fixadd[mb * N + f] = 0.0;
+        if (st != 0.0) S.fixset[mb * N + f] = 0.0;
+      }
+    });
+  };
+  __syncthreads();  // B0
+
+  // ---------------- propagate(s)
+  const int nkp = MP ? S.kp : 1;
+  if (S.do_prop) {
+    // per-lane parts of the operand addresses:  Dblk_T[row = l15][col = lg + 4 s4]  (block diagonal of the five Phi_ff of tile T:
+    // phiff + 45 (T - 1) + 9 (l15 / 3) + 3 (l15 % 3) + col % 3) and the slot of a Z record that k = 4 k6 + lg of the K = 24
+    // coupling reads on either side (viekf_resident_common.hpp); the tile's part of an address is an immediate
+    const int r3 = l15 / 3, rm = l15 - 3 * r3;
+    for (int kp = 0; kp < nkp; kp++) {
+      res_prop_setup<TW>(a, S, tid);   // (B1p, B2p, B2q inside)
+      __syncthreads();  // B3p
+      const double* Z = S.Z;
+      const double* phiff = S.phiff;
+      auto d_op = [&](auto Tc, int s4) -> double {   // Dblk_T[l15][lg + 4 s4]
+        constexpr int Tt = decltype(Tc)::value;
+        const int c = lg + 4 * s4;
+        const bool ok = (l15 < 15) && (c < 15) && (c / 3 == r3) && (5 * (Tt - 1) + r3 < N);
+        const double v = phiff[45 * (Tt - 1) + (ok ? 9 * r3 + 3 * rm + c % 3 : 0)];
+        return ok ? v : 0.0;
+      };
+      auto z_op = [&](auto Tc, int k6, bool iside) -> double {
+        constexpr int Tt = decltype(Tc)::value;
+        const int kk = 4 * k6 + lg;
+        int o = (kk < ZK) ? (2 * kk + 1) : ((kk < 2 * ZK) ? 2 * (kk - ZK) : kk);   // TJ side: D | Ut | Gs
+        if (iside && kk < 2 * ZK) o ^= 1;                                           // TI side: Ut | D | Gs
+        const bool ok = l15 < 15 && 15 * (Tt - 1) + l15 < nf;
+        const double v = Z[(15 * (Tt - 1) + (ok ? l15 : 0)) * ZS + o];
+        return ok ? v : 0.0;
+      };
+      static_for<CNT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+        if (TJ < 1) return;       // (body tiles: in LDS during the propagate, res_prop_body)
+        std::integral_constant<int, TI> ci;
+        std::integral_constant<int, TJ> cj;
+        // X' = D_J X D_I^T + [D_J | Ut_J | Gs_J] [Ut_I | D_I | Gs_I]^T  (vi_ekf.cpp:304 on one tile):
+        //   O1 = X^T D_J^T   (the accumulator registers of X are the A operand of k-step r: that reads X transposed)
+        //   O2 = O1^T D_I^T = D_J X D_I^T, then the K = 24 coupling on the same accumulator
+        v4f64 o1 = {0.0, 0.0, 0.0, 0.0}, o2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s][r], d_op(cj, r), o1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(o1[r], d_op(ci, r), o2, 0, 0, 0);
+#pragma unroll
+        for (int k6 = 0; k6 < 6; k6++) o2 = __builtin_amdgcn_mfma_f64_16x16x4f64(z_op(cj, k6, false), z_op(ci, k6, true), o2, 0, 0, 0);
+        if (TI == TJ) {   // + Qx on the diagonal (every slot, active or not: vi_ekf.cpp:139-144,304)
+          const int pr = tile_prow(TI, l15, nf);
+          const double qx = (pr >= 0) ? a.Qx[max(pr, 0)] : 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (lg + 4 * r == l15) o2[r] += qx;
+        }
+        X[s] = o2;
+        group_fence<true>();   // (one tile's operand loads are not hoisted over the previous tile's: they would all be held live)
+      });
+      if (MP) res_prop_body<TW>(a, S, tid);   // (single propagate: the service wave does this meanwhile)
+      par ^= 1;   // the service wave posted this propagate's fix_depth edits into mailbox par ^ 1
+      if (MP && kp + 1 < nkp) {
+        // the next propagate reads whole diagonal tiles: upper triangle <- lower (what a store and a load in between would
+        // leave: viekf_batch_step_n is bit for bit K propagates and a step), through lane shuffles
+        static_for<CNT>([&](auto sc) {
+          constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+          if (TI != TJ || TI == 0) return;
+          v4f64 nx = X[s];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int aa = lg + 4 * r;                       // element (a = aa, b = l15): P[row b][col a]; upper triangle: b < a
+            const int src = 16 * (l15 & 3) + aa;             // lane that holds (a = l15, b = aa)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+              const double v = __shfl(X[s][rr], src & 63, 64);
+              if (l15 < aa && (l15 >> 2) == rr) nx[r] = v;
+            }
+          }
+          X[s] = nx;
+        });
+      }
+      __syncthreads();  // B4p
+      for (int e = tid; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
+      if (MP && kp + 1 < nkp) apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+    }
+    __syncthreads();  // B4q : the body block copy above is complete
+  }
+
+  // ---------------- body tiles: LDS -> registers (they are swept on the matrix cores like every other tile)
+  static_for<CNT>([&](auto sc) {
+    constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+    if (TJ != 0) return;
+    v4f64 x = {0.0, 0.0, 0.0, 0.0};
+    if (TI == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[r] = Pbb[l15 * 16 + lg + 4 * r];
+    } else {
+      const int fr = 15 * (TI - 1) + l15;
+      if (l15 < 15 && fr < nf) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[r] = Pbc[fr * 16 + lg + 4 * r];
+      }
+    }
+    X[s] = x;
+  });
+
+  // Publishes the column pair of feature g -- P[:, q*], P[:, q* + 1], q* = tile_qrow(g, 0) -- into dst [NQ][2], taken from the
+  // lower triangle only (row i >= column j; the part above the diagonal through its mirror).  The NT tiles that hold it: tile
+  // row T* (TI = T*: its P rows q*, q* + 1 are the wanted columns, mirrored) and tile column T* (TJ = T*).  One scalar jump on T*
+  // reaches the code of exactly this wave's tiles of that cross.
+  auto extract = [&](int g, double* dst) {
+    const int Ts = 1 + g / 5, w0 = 3 * (g % 5);   // (wave-uniform)
+    static_for<NT - 1>([&](auto tc) {
+      constexpr int TS = decltype(tc)::value + 1;
+      if (Ts != TS) return;
+      static_for<CNT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+        if (TI == TS) {
+          const int c = l15 - w0;
+          if (c == 0 || c == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int aa = lg + 4 * r;
+              if (TJ != TS || aa <= l15) dst[2 * (16 * TJ + aa) + c] = X[s][r];
+            }
+          }
+        }
+        if (TJ == TS) {
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const int aa = w0 + c, r = aa >> 2;
+            const double v = (r == 0) ? X[s][0] : ((r == 1) ? X[s][1] : ((r == 2) ? X[s][2] : X[s][3]));
+            if (lg == (aa & 3) && (TI != TS || l15 > aa)) dst[2 * (16 * TI + l15) + c] = v;
+          }
+        }
+      });
+    });
+  };
+
+  // ---------------- M sequential feature updates: covariance side ----------------
+  // (measurement indices and slots are wave-uniform: kept in SGPRs, so that the tests on them are scalar branches)
+  auto uni2 = [](int2 v) { return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y)); };
+  int m = __builtin_amdgcn_readfirstlane(res_next_valid(S, 0));
+  int2 sq = uni2(S.mseq[min(m, S.mcap - 1)]);     // {index of the measurement after m, its slot}
+  if (m < S.M) {
+    apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+    // hand the zeta-zeta 2x2 of every feature to the service lanes (they keep it current from here on): lower triangle, mirrored
+    static_for<CNT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+      if (TI != TJ || TI == 0) return;
+      const int jb = l15 / 3, wb = l15 - 3 * jb, f = 5 * (TI - 1) + jb;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int aa = lg + 4 * r, ja = aa / 3, wa = aa - 3 * ja;
+        if (ja == jb && l15 < 15 && wa < 2 && wb < 2 && wa <= wb && f < N) {   // P[row wb][col wa] of the feature's own block
+          S.Pd[4 * f + 2 * wb + wa] = X[s][r];
+          S.Pd[4 * f + 2 * wa + wb] = X[s][r];
+        }
+      }
+    });
+    extract(__builtin_amdgcn_readfirstlane(S.mslot[m]), S.Cb);   // first measurement: its columns ARE the current ones (nothing pending)
+    if (sq.y >= 0) extract(sq.y, S.Eb + 2 * NQ);     // second one: raw, buffer 1
+  }
+  __syncthreads();  // Bp : Pd and the first columns are published
+  if (m < S.M && tid < NQ) {   // NaN in the first column pair (the later ones are tested where they are formed)
+    const double2 c0 = lds_ld2(S.Cb + 2 * tid);
+    if (c0.x != c0.x || c0.y != c0.y) S.sm[44] = 1.0;
+  }
+  __syncthreads();  // B1 : the service published the first measurement's G and verdict
+  int cnt = 0;
+  // mu = 1 - lambda of this lane's row inside a feature tile / the body tile, folded into the operand factors
+  const double muF = S.mu[16 + l15], muB = S.mu[l15];
+  const double fAF = (lg < 2) ? 1.0 : muF, fAB = (lg < 2) ? 1.0 : muB;        // TJ side:  C[k & 1] x {1, 1, mu, mu}
+  const double fBF = (lg < 2) ? -1.0 : muF, fBB = (lg < 2) ? -1.0 : muB;      // TI side: Kg[k & 1] x {-1, -1, mu, mu}
+  // ONE barrier per update.  Inside a phase the worker waves (1) form their operands from the current column pair C_m and the
+  // 2x2 G_m = Hb^T S^-1 Hb of the service wave and issue one MFMA per tile:  P -= Lambda o (C G C^T)  (= the reference's
+  // (I-KH)P(I-KH)^T + KRK^T - P restricted by Lambda, vi_ekf_meas.cpp:254-257, for K = C Hb^T S^-1), (2) bring the NEXT
+  // measurement's raw column pair -- extracted one phase ago, before this update -- up to date with this update (one row per
+  // thread), (3) extract the raw column pair of the measurement after next from the swept tiles.
+  while (m < S.M) {
+    const int mnext = sq.x, snext = sq.y;
+    const int2 sq2 = uni2(S.mseq[min(mnext, S.mcap - 1)]);
+    const double* mb = S.sm + 8 * (cnt & 1);
+    const double g00 = mb[0], g01 = mb[1], g11 = mb[2];
+    const bool run = mb[3] == 0.0 && S.sm[44 + cnt % 3] == 0.0 && !RES_ABLATE(S, 1);   // not gated, no NaN guard
+    const double fixpending = S.sm[40 + (par ^ 1)];
+    const double* Cc = S.Cb + (cnt & 1) * 2 * NQ;
+    double* Cn = S.Cb + ((cnt + 1) & 1) * 2 * NQ;
+    if (tid == 0) S.sm[44 + (cnt + 2) % 3] = 0.0;   // (the word of the phase after next: nobody reads or sets it in this phase)
+    apply_fixes(par ^ 1, fixpending);
+    if (run) {
+      const bool odd = (lg & 1) != 0;
+      const double ga = odd ? g01 : g00, gb = odd ? g11 : g01;                  // column k & 1 of G
+      const double gaF = ga * fBF, gbF = gb * fBF, gaB = ga * fBB, gbB = gb * fBB;
+      const double* Cl = Cc + 2 * l15;
+      const double* Ck = Cl + (lg & 1);
+      double bop = 0.0;
+      static_for<CNT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+        constexpr int prevTI = (s == 0) ? -1 : Map::ti(W, s == 0 ? 0 : s - 1);
+        if (TI != prevTI) {   // (a wave's slots are ordered by TI: the TI-side operand serves the whole tile row)
+          const double2 cI = lds_ld2(Cl + 32 * TI);
+          bop = (TI == 0) ? fma(cI.y, gbB, cI.x * gaB) : fma(cI.y, gbF, cI.x * gaF);
+        }
+        const double aop = Ck[32 * TJ] * ((TJ == 0) ? fAB : fAF);
+        X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X[s], 0, 0, 0);
+      });
+    }
+    // (2) next measurement's column pair:  C_{m+1}[q] = E[q] - Lambda(q, zeta_c) (C G C^T)[q][zeta_c]
+    if (snext >= 0 && tid < NQ) {
+      const int q = tid, qs = tile_qrow(snext, 0);
+      const double* En = S.Eb + ((cnt + 1) & 1) * 2 * NQ;
+      double2 e = lds_ld2(En + 2 * q);
+      if (run) {
+        const double2 c = lds_ld2(Cc + 2 * q), cs0 = lds_ld2(Cc + 2 * qs), cs1 = lds_ld2(Cc + 2 * qs + 2);
+        const double2 es = lds_ld2(En + 2 * qs);
+        const double mq = S.mu[q], mz0 = S.mu[qs], mz1 = S.mu[qs + 1];
+        const double kg0 = fma(c.y, g01, c.x * g00), kg1 = fma(c.y, g11, c.x * g01);
+        e.x = fma(-fma(-mq, mz0, 1.0), fma(kg1, cs0.y, kg0 * cs0.x), e.x);
+        e.y = fma(-fma(-mq, mz1, 1.0), fma(kg1, cs1.y, kg0 * cs1.x), e.y);
+        // the feature's own 2x2 stays exactly symmetric: element (zeta1, zeta0) takes the value row zeta0 forms for (zeta0, zeta1)
+        const double ks0 = fma(cs0.y, g01, cs0.x * g00), ks1 = fma(cs0.y, g11, cs0.x * g01);
+        const double alt = fma(-fma(-mz0, mz1, 1.0), fma(ks1, cs1.y, ks0 * cs1.x), es.y);
+        if (q == qs + 1) e.x = alt;
+      }
+      *reinterpret_cast<double2*>(Cn + 2 * q) = e;
+      if (e.x != e.x || e.y != e.y) S.sm[44 + (cnt + 1) % 3] = 1.0;
+    }
+    // (3) raw column pair of the measurement after next, from the swept tiles
+    if (sq2.y >= 0 && mnext < S.M && !RES_ABLATE(S, 4)) extract(sq2.y, S.Eb + (cnt & 1) * 2 * NQ);
+    par ^= 1;
+    cnt++;
+    sq = sq2;
+    __syncthreads();  // B1 (the only barrier of an update)
+    m = mnext;
+  }
+  apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+
+  // ---------------- store: the lower triangle, straight from the tiles (lanes along the rows of P) ----------------
+  {
+    double* Po = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
+    static_for<CNT>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+      const int rb = tile_prow(TI, l15, nf);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ca = tile_prow(TJ, lg + 4 * r, nf);
+        if (rb >= 0 && ca >= 0 && (TI != TJ || rb >= ca)) Po[rb + (long)ca * ld] = X[s][r];
+      }
+    });
+  }
+}
+
+}  // namespace viekf
