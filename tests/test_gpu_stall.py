@@ -32,9 +32,8 @@ np.save(sys.argv[1], x)
 def test_stalled_mailbox_raises_internal_flag_and_returns(tmp_path):
     import numpy as np
     lib = str(tmp_path / "libviekf_stall.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
-                           "-Wno-unused-but-set-variable", "-ffp-contract=fast", "-DVIEKF_TEST_STALL", "-shared", "-o", lib,
-                           "viekf_capi.hip", "viekf_yaml.cpp", "viekf_seq.cpp"], cwd=CSRC)
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j", str(min(8, os.cpu_count() or 1)), "OUT=" + lib,
+                           "OBJDIR=" + str(tmp_path / "obj"), "EXTRA=-DVIEKF_TEST_STALL"])
     script = str(tmp_path / "child.py")
     open(script, "w").write(CHILD % ROOT)
     outs = {}

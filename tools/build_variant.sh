@@ -1,9 +1,10 @@
 #!/bin/bash
 # builds the library of the current tree into variants/lib_<name>.so (A/B timing of two variants on ONE gpurun box:
-# VIEKF_LIB=variants/lib_<name>.so python bench.py ...)
+# VIEKF_LIB=variants/lib_<name>.so python bench.py ...); extra compiler flags as further arguments, e.g.
+#   tools/build_variant.sh stamps -DVIEKF_STAMPS        tools/build_variant.sh ablate -DVIEKF_ABLATE
 set -e
+name=$1; shift
 cd "$(dirname "$0")/../vi_ekf_amd/csrc"
 mkdir -p ../../variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-but-set-variable -ffp-contract=fast -shared \
-  -o ../../variants/lib_$1.so viekf_capi.hip viekf_yaml.cpp viekf_seq.cpp 2>&1 | grep -E "error" || true
-ls -la ../../variants/lib_$1.so
+make -s -j8 OUT=../../variants/lib_$name.so OBJDIR=../../build/obj_$name EXTRA="$*"
+ls -la ../../variants/lib_$name.so

@@ -22,5 +22,6 @@ def stale():
 
 def build(force=False):
     if force or stale():
-        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+        jobs = str(max(1, min(8, os.cpu_count() or 1)))
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j", jobs] + (["-B"] if force else []))
     return LIB

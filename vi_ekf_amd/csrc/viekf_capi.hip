@@ -14,8 +14,15 @@
 
 #include "../../include/viekf.h"
 #include "viekf_host.hpp"
-#include "viekf_kernels_resident.hpp"
-#include "viekf_kernels_tiles.hpp"
+#include "viekf_instances.hpp"
+
+// (the fused-step kernels are compiled in viekf_inst.hip, one object file per group of instances)
+#define RES_EXT(RB, NW, NS) VIEKF_RES_FLAVOURS(extern, RB, NW, NS)
+#define TILE_EXT(NT, NW) VIEKF_TILE_FLAVOURS(extern, NT, NW)
+VIEKF_RES_LIST(RES_EXT)
+VIEKF_TILE_LIST(TILE_EXT)
+#undef RES_EXT
+#undef TILE_EXT
 
 using namespace viekf;
 

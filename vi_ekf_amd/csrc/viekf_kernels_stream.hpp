@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(T) void k_eval_xdot(StreamArgs a, const double* __r
 
 // zhat [B][4] of measurement model `type` at the current state (one thread per filter); unused entries and filters whose
 // slot is out of range get NaN
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_eval_h(StreamArgs a, int type, const int* __restrict__ slot_all, double* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
@@ -1107,9 +1108,11 @@ __global__ void k_eval_h(StreamArgs a, int type, const int* __restrict__ slot_al
   }
   for (int i = 0; i < 4; i++) out[(long)b * 4 + i] = zhat[i];
 }
+#endif
 
 // P <- (P + P^T) / 2 of every filter (a covariance handed in through viekf_batch_set_state): the kernels keep P exactly
 // symmetric from then on and rely on it
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_symmetrize(StreamArgs a) {
   const int b = blockIdx.y;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1121,9 +1124,11 @@ __global__ void k_symmetrize(StreamArgs a) {
   P[i + (long)j * a.ld] = v;
   P[j + (long)i * a.ld] = v;
 }
+#endif
 
 // upper triangle <- lower triangle (bit for bit), 32 x 32 tiles through LDS so that both sides are coalesced along the rows.
 // Runs when a grouped update left the upper triangle stale (k_update_feat_blocked) and something is about to read all of P.
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
   __shared__ double t[32][33];
   const int b = blockIdx.y, n = a.n, nt = (n + 31) >> 5;
@@ -1145,15 +1150,19 @@ __global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
     if (i < n && j < n && i < j) P[i + (long)j * a.ld] = t[lx][c];   // (a diagonal tile: its strictly upper part only)
   }
 }
+#endif
 
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
   const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
 }
+#endif
 
 // per-filter history: copies (x, P) of filter b between the batch's live buffers and ring slot slot[b] (< 0: filter skipped);
 // to_ring != 0: live -> ring.  Filters on independent clocks advance and rewind their rings separately (viekf_seq, independent
 // mode); the feature counts are not part of a slot, as in the reference's ring (include/vi_ekf.h:156-160).
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restrict__ ring_x, double* __restrict__ ring_P,
                                                    const int* __restrict__ slot, int to_ring, int depth) {
   const int b = blockIdx.x;
@@ -1174,14 +1183,17 @@ __global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restr
   for (long e = threadIdx.x; e < nP / 2; e += 256) dst[e] = src[e];
   for (int e = threadIdx.x; e < a.nxs; e += 256) (to_ring ? rx : lx)[e] = (to_ring ? lx : rx)[e];
 }
+#endif
 
 // a rectangular block P[r0 .. r0+nr, c0 .. c0+nc) of every filter -> out [B][nc][nr] (column-major per filter)
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_cov_block(StreamArgs a, int r0, int c0, int nr, int nc, double* __restrict__ out) {
   const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B || e >= nr * nc) return;
   const int c = e / nr, r = e - c * nr;
   out[(long)b * nr * nc + e] = a.P[(long)b * a.n * a.ld + (r0 + r) + (long)(c0 + c) * a.ld];
 }
+#endif
 
 template <int T>
 __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, int zdim, int rdim,
@@ -1509,6 +1521,7 @@ __global__ __launch_bounds__(T) void k_keyframe_reset(StreamArgs a, const unsign
 }
 
 // fill every filter with the initial state (vi_ekf.cpp:70-81 / :134-144)
+#ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, const double* __restrict__ Pdiag /*n*/) {
   const int b = blockIdx.x;
   if (b >= a.B) return;
@@ -1522,5 +1535,6 @@ __global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, cons
   }
   if (threadIdx.x == 0) { a.len[b] = 0; a.flags[b] = 0; }
 }
+#endif
 
 }  // namespace viekf

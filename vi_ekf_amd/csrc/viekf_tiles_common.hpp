@@ -27,7 +27,7 @@ namespace viekf {
 __host__ __device__ inline int tile_nt(int N) { return 1 + (N + 4) / 5; }
 
 struct TileLds {  // LDS carve-up in doubles, shared by host (size) and device (offsets)
-  int xs, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, PhibbT, Gdb, T16, PsiP, Pi, Xi, AvG, Cb, Eb, Pd, Mbb, Pbb, xdb, ctx, Pbc, mu,
+  int xs, lam, sm, fixadd, fixset, Z, phiff, Abb, Gb, Phibb, PhibbT, Gdb, T16, PsiP, Pi, Xi, AvG, Cb, Eb, Pd, Mbb, Pbb, xdb, ctx, Pbc,
       mslot, mseq, mz, mR, total;
   __host__ __device__ TileLds(int N, int n, int nxs) {
     const int nf = 3 * N, NQ = 16 * tile_nt(N);
@@ -35,7 +35,6 @@ struct TileLds {  // LDS carve-up in doubles, shared by host (size) and device (
     auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
     xs = take(nxs);
     lam = take(n);
-    mu = take(NQ);          // 1 - lambda per tile-space row (pad rows: 0)
     sm = take(64);          // [0..15] two measurement mailboxes {g00, g01, g11, skip}; [40..41] fix mailboxes non-empty; [42] dt;
                             // [44..46] NaN-in-column words (phase mod 3)
     fixadd = take(2 * (N > 0 ? N : 1)); fixset = take(2 * (N > 0 ? N : 1));
@@ -62,7 +61,7 @@ struct TileLds {  // LDS carve-up in doubles, shared by host (size) and device (
 };
 
 struct TileShared : ResShared {   // (the propagate set-up routines of the resident family work on the ResShared part)
-  double *Cb, *Eb, *mu;
+  double *Cb, *Eb;
   int NT, NQ;
 };
 
@@ -71,6 +70,11 @@ __device__ __forceinline__ int tile_prow(int T, int w, int nf) {
   if (T == 0) return w;
   const int r = 15 * (T - 1) + w;
   return (w < 15 && r < nf) ? 16 + r : -1;
+}
+// mu = 1 - lambda of a tile-space row (0 for a pad row and without the partial update):  Lambda_ij = 1 - mu_i mu_j
+__device__ __forceinline__ double tile_mu(const double* lam, int q, int nf, bool partial) {
+  const int pr = tile_prow(q >> 4, q & 15, nf);
+  return (pr >= 0 && partial) ? 1.0 - lam[max(pr, 0)] : 0.0;
 }
 // tile-space row index of row r of feature f
 __device__ __forceinline__ int tile_qrow(int f, int r) { return 16 * (1 + f / 5) + 3 * (f % 5) + r; }
@@ -84,7 +88,7 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
                                               int* __restrict__ result_all) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const TileLds L(a.N, a.n, a.nxs);
-  S.xs = smem + L.xs; S.lam = smem + L.lam; S.mu = smem + L.mu; S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset;
+  S.xs = smem + L.xs; S.lam = smem + L.lam; S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset;
   S.Z = smem + L.Z; S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
   S.Gdb = smem + L.Gdb; S.Pbb = smem + L.Pbb; S.T16 = smem + L.T16; S.xdb = smem + L.xdb; S.Pbc = smem + L.Pbc; S.PhibbT = smem + L.PhibbT;
   S.Pd = smem + L.Pd; S.PsiP = smem + L.PsiP; S.Pi = smem + L.Pi; S.Xi = smem + L.Xi; S.AvG = smem + L.AvG;
@@ -101,11 +105,6 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
     const double* xg = a.x + (long)b * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
-    const bool partial = a.dp->use_partial_update != 0;
-    for (int q = tid; q < S.NQ; q += T) {
-      const int pr = tile_prow(q >> 4, q & 15, S.nf);
-      S.mu[q] = (pr >= 0 && partial) ? 1.0 - a.lambda[pr] : 0.0;
-    }
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
     for (int i = tid; i < 64; i += T) S.sm[i] = (i == 42 && (do_prop & 1)) ? dt_all[b] : 0.0;
     for (int mm_ = tid; mm_ < M; mm_ += T) {

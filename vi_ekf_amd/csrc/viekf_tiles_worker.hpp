@@ -280,7 +280,10 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   __syncthreads();  // B1 : the service published the first measurement's G and verdict
   int cnt = 0;
   // mu = 1 - lambda of this lane's row inside a feature tile / the body tile, folded into the operand factors
-  const double muF = S.mu[16 + l15], muB = S.mu[l15];
+  const bool partial = prm.use_partial_update != 0;
+  const double muF = tile_mu(S.lam, 16 + l15, nf, partial), muB = tile_mu(S.lam, l15, nf, partial);
+  const double mq_own = tile_mu(S.lam, min(tid, NQ - 1), nf, partial);                         // of the row this thread brings up to date
+  const double mz0 = tile_mu(S.lam, 16, nf, partial), mz1 = tile_mu(S.lam, 17, nf, partial);   // lambda_feat is the same for every slot
   const double fAF = (lg < 2) ? 1.0 : muF, fAB = (lg < 2) ? 1.0 : muB;        // TJ side:  C[k & 1] x {1, 1, mu, mu}
   const double fBF = (lg < 2) ? -1.0 : muF, fBB = (lg < 2) ? -1.0 : muB;      // TI side: Kg[k & 1] x {-1, -1, mu, mu}
   // ONE barrier per update.  Inside a phase the worker waves (1) form their operands from the current column pair C_m and the
@@ -325,7 +328,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
       if (run) {
         const double2 c = lds_ld2(Cc + 2 * q), cs0 = lds_ld2(Cc + 2 * qs), cs1 = lds_ld2(Cc + 2 * qs + 2);
         const double2 es = lds_ld2(En + 2 * qs);
-        const double mq = S.mu[q], mz0 = S.mu[qs], mz1 = S.mu[qs + 1];
+        const double mq = mq_own;
         const double kg0 = fma(c.y, g01, c.x * g00), kg1 = fma(c.y, g11, c.x * g01);
         e.x = fma(-fma(-mq, mz0, 1.0), fma(kg1, cs0.y, kg0 * cs0.x), e.x);
         e.y = fma(-fma(-mq, mz1, 1.0), fma(kg1, cs1.y, kg0 * cs1.x), e.y);
