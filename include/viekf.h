@@ -185,6 +185,28 @@ int viekf_batch_keyframe_reset(viekf_batch *b, const uint8_t *mask, double *edge
 int viekf_batch_eval_xdot(viekf_batch *b, const double *u, double *xdot, viekf_mem where);
 int viekf_batch_eval_h(viekf_batch *b, int32_t type, const int32_t *slot, double *zhat, viekf_mem where);
 int viekf_batch_get_cov_diag(viekf_batch *b, double *diag, viekf_mem where);
+/* VIEKF::set_drag_term / get_drag_term (include/vi_ekf.h:290-291): the drag term of the dynamics and of the accelerometer model
+ * (src/vi_ekf/vi_ekf_dyn.cpp:44-49,57-67,74-77; vi_ekf_meas.cpp:281-306) is a RUN-TIME switch -- vi_ekf_ros starts with it off and turns
+ * it on after take-off (src/vi_ekf_ros.cpp:86,428-429).  Takes effect for every launch after the call. */
+int viekf_batch_set_drag_term(viekf_batch *b, int32_t use_drag_term);
+int viekf_batch_get_drag_term(const viekf_batch *b, int32_t *use_drag_term);
+
+/* The reference's public TEST HOOKS, evaluated on the device with the device functions the hot kernels use; dense outputs in the
+ * reference's (Eigen, column-major) layouts.  None changes the filter.  x / xm / x1 / x2 [batch][nx] are explicit states (for
+ * eval_jacobians and eval_H: NULL = the batch's current state); the feature loops run to the batch's current len_features.
+ *   eval_jacobians   dynamics(x, u, xdot, dfdx, dfdu), src/vi_ekf/vi_ekf_dyn.cpp:5-134: u [batch][6] is the BODY-frame input as that
+ *                    overload takes it (not rotated by q_b_u; propagate_state does that first, vi_ekf.cpp:265-267);
+ *                    xdot [batch][n], A [batch][n][n] (n x n column-major), G [batch][6][n] (n x 6 column-major); any of the three NULL
+ *   eval_H           h_<type>(x, h, H, id), src/vi_ekf/vi_ekf_meas.cpp:281-386: zhat [batch][4], H [batch][n][3] (the 3 x n hMatrix,
+ *                    column-major); slot [batch] for QZETA / FEAT / DEPTH / INV_DEPTH (a slot that is not an active feature: NaN, H = 0)
+ *   boxplus          boxplus(x, dx, out), src/vi_ekf/vi_ekf_helper.cpp:88-98: dx [batch][n], out [batch][nx]
+ *   boxminus         boxminus(x1, x2, out), :100-111: out [batch][n]
+ *   eval_reset_jacobian   keyframe_reset(xm, xp, N), src/vi_ekf/vi_ekf_kfr.cpp:6-12: xp [batch][nx], N [batch][n][n]; either NULL */
+int viekf_batch_eval_jacobians(viekf_batch *b, const double *x, const double *u, double *xdot, double *A, double *G, viekf_mem where);
+int viekf_batch_eval_h_jacobian(viekf_batch *b, const double *x, int32_t type, const int32_t *slot, double *zhat, double *H, viekf_mem where);
+int viekf_batch_boxplus(viekf_batch *b, const double *x, const double *dx, double *out, viekf_mem where);
+int viekf_batch_boxminus(viekf_batch *b, const double *x1, const double *x2, double *out, viekf_mem where);
+int viekf_batch_eval_reset_jacobian(viekf_batch *b, const double *xm, double *xp, double *N, viekf_mem where);
 /* a rectangular block of P of every filter, out [batch][ncols][nrows] (column-major per filter): what get_global_cov reads
  * of P_ (P_.block<3,3>(xPOS|xATT, xPOS|xATT), src/vi_ekf/vi_ekf_kfr.cpp:28-31) without moving the whole covariance */
 int viekf_batch_get_cov_block(viekf_batch *b, int32_t row0, int32_t col0, int32_t nrows, int32_t ncols, double *out,
@@ -282,9 +304,31 @@ int viekf_seq_handle_measurements(viekf_seq *s, int32_t *gated_ids, int32_t cap,
  * triggered by the overlap test and their edges (viekf_batch_keyframe_reset) */
 int viekf_seq_keep_only_features(viekf_seq *s, const int32_t *ids, int32_t count, uint8_t *did_reset, double *edges);
 int viekf_seq_tracked_features(viekf_seq *s, int32_t *ids /* [batch][num_features] */, int32_t *len /* [batch] */);
+/* VIEKF::clear_feature (src/vi_ekf/vi_ekf_feat.cpp:50-73) for every tracked feature NOT in keep_ids [batch][count] (pad with -1): the
+ * removal part of keep_only_features without its keyframe-overlap test */
+int viekf_seq_drop_features(viekf_seq *s, const int32_t *keep_ids, int32_t count);
 /* pix [batch][2]; depth [batch] (NULL = NaN -> 2 min_depth); mask [batch] (NULL = all); ok [batch] (may be NULL): 1 if a slot was taken */
 int viekf_seq_init_feature(viekf_seq *s, const double *pix, const double *depth, const uint8_t *mask, int32_t *ok);
 int viekf_seq_status(viekf_seq *s, double *t_now, int32_t *ring_index, int32_t *queued, int32_t *inputs);
+/* The remaining members of the reference class that its callers use (include/vi_ekf.h:271-292,302,324):
+ *   viekf_seq_propagate_state   propagate_state(u, t, save_input)  (save_input = 0: the input is not recorded in the input queue
+ *                               and the step is not logged, src/vi_ekf/vi_ekf.cpp:269-272,316-317; shared clock only)
+ *   viekf_seq_set_x0            set_x0: x_[i_].topRows(17) = x0 [batch][17]                      vi_ekf.cpp:157-160
+ *   viekf_seq_set_imu_bias      set_imu_bias(b_g, b_a), [batch][3] each, into the LIVE state    vi_ekf.cpp:179-183
+ *   viekf_seq_keyframe_reset    keyframe_reset(): explicit reset of the filters with mask[b] != 0 (NULL = all) including the node
+ *                               frame's move (vi_ekf_kfr.cpp:56-157; vi_ekf_ros calls it right after set_x0, src/vi_ekf_ros.cpp:401-402);
+ *                               edges [batch][17] as viekf_batch_keyframe_reset, may be NULL.  The callback of
+ *                               register_keyframe_reset_callback is the binding's (include/viekf_shim.hpp).
+ *   viekf_seq_get_features      get_depths / get_zetas / get_qzetas / get_zeta                  vi_ekf.cpp:210-246
+ *                               depths [batch][N], zetas [batch][N][3], qzetas [batch][N][4]; NaN past a filter's features; any NULL
+ *   viekf_seq_get_feat          get_feat(id) / get_depth(id) by global feature id [batch]       vi_ekf.cpp:248-260
+ *                               pix [batch][2], depth [batch]; NaN for an id the filter does not track; either may be NULL */
+int viekf_seq_propagate_state(viekf_seq *s, const double *u, double t, int32_t save_input);
+int viekf_seq_set_x0(viekf_seq *s, const double *x0);
+int viekf_seq_set_imu_bias(viekf_seq *s, const double *b_g, const double *b_a);
+int viekf_seq_keyframe_reset(viekf_seq *s, const uint8_t *mask, double *edges);
+int viekf_seq_get_features(viekf_seq *s, double *depths, double *zetas, double *qzetas);
+int viekf_seq_get_feat(viekf_seq *s, const int32_t *id, double *pix, double *depth);
 
 /* Global pose and covariance (relative navigation: the filter state is relative to the last keyframe node).
  *   viekf_seq_get_global_pose   VIEKF::get_global_pose, get_current_node_global_pose   src/vi_ekf/vi_ekf_kfr.cpp:14-21, vi_ekf.cpp:192-195

@@ -245,6 +245,28 @@ class SeqOracle:
             self.u.pop()
         return gated
 
+    # -- setters and the explicit keyframe reset that callers use (include/vi_ekf.h:288-292,324) ----------------------------
+    def set_x0(self, x0):                                   # vi_ekf.cpp:157-160: x_[i_].topRows(xZ) = x0
+        self.f.x[:17] = np.asarray(x0, dtype=np.float64)
+        self._save()
+
+    def set_imu_bias(self, b_g, b_a):                       # vi_ekf.cpp:179-183
+        self.f.x[13:16] = np.asarray(b_g, dtype=np.float64)
+        self.f.x[10:13] = np.asarray(b_a, dtype=np.float64)
+        self._save()
+
+    def set_drag_term(self, on):                            # include/vi_ekf.h:290
+        self.f.set_drag_term(bool(on))
+
+    def keyframe_reset(self):                               # vi_ekf_kfr.cpp:56-157 (state, N P N^T, the node frame's move)
+        self.keyframe_edges.append(self.f.keyframe_reset_edge())
+        self._node_update(self.keyframe_edges[-1])
+        self._save()
+
+    def clear_feature(self, gid):                           # vi_ekf_feat.cpp:50-73
+        self.f.clear_feature(int(gid))
+        self._save()
+
     # -- vi_ekf_feat.cpp:81-142 -----------------------------------------------------------------------------------------
     def keep_only_features(self, features):
         features = [int(v) for v in features]

@@ -49,14 +49,14 @@ int main(int argc, char** argv) {
   FILE* o = std::fopen(argv[4], "wb");
   if (!o) return 6;
   auto put = [&](const double* p, size_t n) { std::fwrite(p, sizeof(double), n, o); };
-  const std::vector<double>& x = ekf.get_state();
-  const std::vector<double>& P = ekf.get_covariance();
+  const vi_ekf::VIEKF::Vec& x = ekf.get_state();
+  const vi_ekf::VIEKF::Mat& P = ekf.get_covariance();
   const std::vector<int>& tr = ekf.tracked_features();
   double hdr[6] = {(double)x.size(), (double)ekf.max_dx(), (double)ekf.get_len_features(), (double)tr.size(), (double)gated.size(),
                    (double)results.size()};
   put(hdr, 6);
-  put(x.data(), x.size());
-  put(P.data(), P.size());
+  put(x.data(), (size_t)x.size());
+  put(P.data(), (size_t)P.size());
   for (int v : tr) { double d = v; put(&d, 1); }
   for (int v : gated) { double d = v; put(&d, 1); }
   put(results.data(), results.size());

@@ -136,3 +136,160 @@ def test_cpp_shim_flight_matches_restated_plumbing(tmp_path):
     assert np.abs(P - o.f.P).max() <= tol(o.f.P)
     assert np.abs(node - o.node).max() <= tol(o.node) and np.abs(gpose - o.get_global_pose()).max() <= 1e-9
     assert np.abs(cov - o.get_global_cov()).max() <= tol(o.get_global_cov())
+
+
+def build_callsites(tmp):
+    exe = os.path.join(str(tmp), "shim_callsites")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_callsites.cpp")] + LINK)
+    return exe
+
+
+def test_reference_call_expressions_compile_against_the_shim(tmp_path):
+    """the call expressions of src/vi_ekf_ros.cpp and test/vi_ekf_test.cpp, on a mock of the Eigen types, build warning-free"""
+    from vi_ekf_amd import _build
+    _build.build()
+    build_callsites(tmp_path)
+
+
+@pytest.mark.gpu
+def test_reference_call_sites_flight_matches_restated_plumbing(tmp_path):
+    """tests/cpp/shim_callsites.cpp: the adapter's callbacks (IMU with the accelerometer model chosen by get_drag_term, camera
+    frames with FEAT + DEPTH entries, truth POS / ATT / VEL / ALT, first-truth set_x0 + keyframe_reset, the drag term switched on
+    in flight, set_imu_bias, clear_feature) against oracle/seq_oracle.py doing the same; every getter of include/vi_ekf.h:271-292"""
+    exe = build_callsites(tmp_path)
+    N = 6
+    prm, full = yaml_params()
+    o = so.SeqOracle(orc.OracleFilter(N).init(**prm), float(full["keyframe_overlap_threshold"]))
+    o.set_drag_term(False)                                   # vi_ekf_ros.cpp:86
+    rng = np.random.default_rng(23)
+    ev, results, gated = [], [], []
+    I2, I3 = np.eye(2), np.eye(3)
+    R = dict(acc_drag=0.5 * I2, acc_grav=0.5 * I3, att=0.01 * I3, pos=0.01 * I3, feat=10.0 * I2, alt=np.array([[0.05]]),
+             depth=np.array([[0.1]]), vel=1e-8 * I3)
+    drag = [False]
+
+    def rec(code, t, *payload, last=None):
+        e = np.zeros(32)
+        e[0], e[1] = code, t
+        e[2:2 + len(payload)] = payload
+        if last is not None:
+            e[31] = last
+        ev.append(e)
+
+    def imu_cb(t, imu, use_acc, is_flying, q_att, use_imu_att):
+        rec(1, t, *imu, float(use_acc), float(is_flying), *q_att, float(use_imu_att))
+        o.propagate_state(imu, t)
+        if drag[0]:
+            results.append(o.add_measurement(t, imu[0:2], orc.ACC, R["acc_drag"], use_acc and is_flying))
+        else:
+            nrm = np.linalg.norm(imu[0:3])
+            if 9.80665 * 0.85 < nrm < 9.80665 * 1.15:
+                results.append(o.add_measurement(t, imu[0:3], orc.ACC, R["acc_grav"], use_acc))
+        if use_imu_att:
+            results.append(o.add_measurement(t, q_att, orc.ATT, R["att"], True))
+
+    def frame_cb(t, ids, pixs, depths, use_depth):
+        payload = [len(ids)]
+        for i, p, d in zip(ids, pixs, depths):
+            payload += [i, p[0], p[1], d]
+        rec(2, t, *payload, last=float(use_depth))
+        for i, p, d in zip(ids, pixs, depths):
+            d32 = float(np.float32(d))
+            res = o.add_measurement(t, p, orc.FEAT, R["feat"], True, i, d32 if use_depth else float("nan"))
+            results.append(res)
+            if res == orc.MEAS_SUCCESS and not np.isnan(d32):
+                results.append(o.add_measurement(t, [d32], orc.DEPTH, R["depth"], use_depth, i))
+        gated.extend(o.handle_measurements())
+
+    def truth_cb(t, z_pos, z_att, truth_active, is_flying, z_alt):
+        rec(3, t, *z_pos, *z_att, float(truth_active), float(is_flying), z_alt)
+        results.append(o.add_measurement(t, z_pos, orc.POS, R["pos"], truth_active))
+        results.append(o.add_measurement(t, z_att, orc.ATT, R["att"], truth_active))
+        gated.extend(o.handle_measurements())
+        if not is_flying:
+            results.append(o.add_measurement(t, np.zeros(3), orc.VEL, R["vel"], True))
+        results.append(o.add_measurement(t, [z_alt], orc.ALT, R["alt"], not truth_active))
+
+    pix = rng.uniform(150, 450, (N, 2))
+    q0 = orc.q_boxplus(np.array([1.0, 0, 0, 0]), np.array([0.02, -0.03, 0.4]))
+    u0 = np.array([0.0, 0.0, -9.80665, 0.0, 0.0, 0.0])
+    rec(7, 0.0, *u0)                                         # test/vi_ekf_test.cpp:24-27 (the first sample only starts the clock)
+    o.propagate_state(u0, 0.0, True)
+    rec(5, 0.0, 0.5, -0.3, -1.0, *q0)                        # first truth message: set_x0 + keyframe_reset
+    x0 = o.f.x[:17].copy()
+    x0[0:3] = [0.5, -0.3, -1.0]
+    x0[6:10] = q0
+    o.set_x0(x0)
+    o.keyframe_reset()
+    ids_all = list(range(N))
+    for k in range(1, 46):
+        t = 0.004 * k
+        imu = u0 + rng.normal(0, 0.15, 6)
+        qa = orc.q_boxplus(q0, rng.normal(0, 0.01, 3))
+        imu_cb(t, imu, True, k > 10, qa, k % 7 == 3)
+        if k % 6 == 2:
+            tz = t - 0.0105 if k > 6 else t                  # a delayed frame: rewind + replay
+            ids = ids_all if k < 30 else [0, 2, 5]
+            frame_cb(tz, ids, [pix[i] + rng.normal(0, 0.5, 2) for i in ids], [3.0 + 0.5 * i + rng.normal(0, 0.05) for i in ids],
+                     k % 12 == 8)
+        if k % 9 == 4:
+            truth_cb(t, np.array([0.0, 0.0, 0.0]) + rng.normal(0, 0.02, 3), orc.q_boxplus(o.f.x[6:10], rng.normal(0, 0.01, 3)),
+                     k < 27, k > 10, float(-o.f.x[2] + rng.normal(0, 0.05)))
+        if k == 20:
+            rec(6, t)                                        # take-off + 10 s: the drag term comes on (vi_ekf_ros.cpp:428-429)
+            o.set_drag_term(True)
+            drag[0] = True
+        if k == 25:
+            bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
+            rec(8, t, *bg, *ba)
+            o.set_imu_bias(bg, ba)
+        if k == 30:
+            rec(4, t, 3, 0, 2, 5)                            # 3 of 6 < 0.8: features 1, 3, 4 dropped, keyframe reset
+            o.keep_only_features([0, 2, 5])
+        if k == 38:
+            rec(9, t, 2)
+            o.clear_feature(2)
+    # (with several measurement streams in one queue the replay walks over entries it has already handled: the reference prints
+    #  this and moves on, vi_ekf_meas.cpp:87-90 -- nothing else may have been logged)
+    assert set(o.log) <= {"trying to handle measurement again"}, set(o.log)
+    evf, outf = str(tmp_path / "events.bin"), str(tmp_path / "out.bin")
+    np.stack(ev).tofile(evf)
+    r = subprocess.run([exe, YAML, str(N), evf, outf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a = np.fromfile(outf)
+    nx, n, ln, ntr, ng, nres = (int(c) for c in a[:6])
+    assert (nx, n, ln) == (17 + 5 * N, 16 + 3 * N, o.f.len_features) and ln == 2
+    q = 6
+    x = a[q:q + nx]; q += nx
+    P = a[q:q + n * n].reshape(n, n, order="F"); q += n * n
+    tracked = a[q:q + ntr].astype(int).tolist(); q += ntr
+    got_gated = a[q:q + ng].astype(int).tolist(); q += ng
+    res = a[q:q + nres]; q += nres
+    gpose, node, cov = a[q:q + 7], a[q + 7:q + 14], a[q + 14:q + 50].reshape(6, 6, order="F")
+    q += 50
+    depths = a[q:q + ln]; q += ln
+    zetas = a[q:q + 3 * ln].reshape(3, ln, order="F"); q += 3 * ln
+    qzetas = a[q:q + 4 * ln].reshape(4, ln, order="F"); q += 4 * ln
+    assert tracked == list(o.f.feature_ids) == [0, 5]
+    assert res.tolist() == [float(v) for v in results]
+    assert got_gated == [int(g) for g in gated]
+    tol = lambda ref: 1e-9 * max(np.abs(ref).max(), 1e-300)
+    assert np.abs(x - o.f.x).max() <= tol(o.f.x)
+    assert np.abs(P - o.f.P).max() <= tol(o.f.P)
+    assert np.abs(node - o.node).max() <= tol(o.node) and np.abs(gpose - o.get_global_pose()).max() <= 1e-9
+    assert np.abs(cov - o.get_global_cov()).max() <= tol(o.get_global_cov())
+    F = np.asarray(prm["focal_len"]); c = np.asarray(prm["cam_center"])
+    for j, gid in enumerate(tracked):
+        f5 = o.f.x[17 + 5 * j:22 + 5 * j]
+        zeta = orc.q_rota(f5[:4], [0, 0, 1.0])
+        assert abs(depths[j] - 1.0 / f5[4]) <= 1e-9 * abs(1.0 / f5[4])              # get_depths, vi_ekf.cpp:210-218
+        assert np.abs(zetas[:, j] - zeta).max() <= 1e-9 and np.abs(qzetas[:, j] - f5[:4]).max() <= 1e-9   # :220-239
+        px, dd, zi = a[q:q + 2], a[q + 2], a[q + 3:q + 6]; q += 6
+        assert np.abs(px - (F * zeta[:2] / zeta[2] + c)).max() <= 1e-6                # get_feat, :253-260
+        assert abs(dd - 1.0 / f5[4]) <= 1e-9 * abs(dd) and np.abs(zi - zeta).max() <= 1e-9   # get_depth, get_zeta
+    dg = a[q:q + n]; q += n
+    assert np.abs(dg - np.diag(o.f.P)).max() <= tol(np.diag(o.f.P))
+    resets, flags, drag_on, kfr = a[q:q + 4]
+    assert int(resets) == len(o.keyframe_edges) == 2          # the explicit one and the overlap-triggered one
+    assert int(flags) == 0 and drag_on == 1.0 and kfr == 1.0

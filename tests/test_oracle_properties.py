@@ -3,213 +3,60 @@
 Mirrors /root/reference/test/jac_test.cpp (manifold :245-280, dfdx :306-365, dfdu :367-415,
 h_test :417-443, KF_reset :446-487) with the same tolerances.  These properties are what pins
 the oracle's conventions (active/passive rotation, right-[+] attitude, left-[+] bearing, T_zeta):
-the reference has no stored vectors ("parity unpinned").
+the reference has no stored vectors ("parity unpinned").  The checks themselves live in tests/properties.py
+and also run against the device (tests/test_gpu_properties.py).
 """
 import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests.helpers import jac_fixture, make_oracle
-
-NUM_ITERS = 12
-NS = [3, 12]
+from tests import properties as prop
+from tests.helpers import make_oracle
 
 
-def _sign(x):
-    return 1.0 if x >= 0 else -1.0
+class OracleAdapter:
+    """the filter interface of tests/properties.py over oracle.OracleFilter"""
+
+    def __init__(self, N, params, pix, depth):
+        self.f = make_oracle(N, params, pix, depth)
+        self.x, self.n, self.len_features = self.f.x, self.f.n, self.f.len_features
+
+    def boxplus(self, x, dx): return self.f.boxplus(x, dx)
+    def boxminus(self, x1, x2): return self.f.boxminus(x1, x2)
+    def dynamics(self, x, u): return self.f.dynamics(x, u)
+    def h(self, mtype, x, id): return self.f.h(mtype, x, id)
+    def set_drag_term(self, on): self.f.set_drag_term(on)
+
+    def reset_map(self, xm):
+        g = self.f.clone()
+        g.x[:] = xm
+        g.keyframe_reset()
+        return g.x.copy(), g.A.copy()
 
 
-def _xvector_equal(f, x1, x2, N):
-    # XVECTOR_EQUAL, jac_test.cpp:228-243
-    np.testing.assert_allclose(x1[:6], x2[:6], atol=1e-8, rtol=0)
-    q1, q2 = x1[6:10], x2[6:10]
-    if _sign(q1[0]) != _sign(q2[0]):
-        q1 = -q1
-    np.testing.assert_allclose(q1, q2, atol=1e-8, rtol=0)
-    np.testing.assert_allclose(x1[10:17], x2[10:17], atol=1e-8, rtol=0)
-    for i in range(N):
-        z1 = orc.q_rota(x1[17 + 5 * i:21 + 5 * i], [0, 0, 1.0])
-        z2 = orc.q_rota(x2[17 + 5 * i:21 + 5 * i], [0, 0, 1.0])
-        np.testing.assert_allclose(z1, z2, atol=1e-8, rtol=0)
-        # (the reference compares x1 rho with itself, :241; we compare properly)
-        assert abs(x1[21 + 5 * i] - x2[21 + 5 * i]) < 1e-8
-
-
-@pytest.mark.parametrize("N", NS)
+@pytest.mark.parametrize("N", prop.NS)
 def test_manifold(N):
-    r = np.random.default_rng(1234 + N)
-    for j in range(NUM_ITERS):
-        p, pix, dep, _ = jac_fixture(N, 1000 + j)
-        f = make_oracle(N, p, pix, dep)
-        x = f.x.copy()
-        p2, pix2, dep2, _ = jac_fixture(N, 5000 + j)
-        x2 = make_oracle(N, p2, pix2, dep2).x.copy()
-        # (x [+] 0) == x
-        np.testing.assert_allclose(f.boxplus(x, np.zeros(f.n)), x, atol=1e-8, rtol=0)
-        # (x [+] (x2 [-] x)) == x2
-        x3 = f.boxplus(x, f.boxminus(x2, x))
-        _xvector_equal(f, x3, x2, N)
-        # ((x [+] dx) [-] x) == dx
-        dx = r.uniform(-1, 1, f.n)
-        np.testing.assert_allclose(f.boxminus(f.boxplus(x, dx), x), dx, atol=1e-8, rtol=0)
-        # ||(x [+] dx1) [-] (x [+] dx2)|| <= ||dx1 - dx2||  (reference asserts against (dx - dx2), :277)
-        dx1, dx2 = r.uniform(-1, 1, f.n), r.uniform(-1, 1, f.n)
-        d = f.boxminus(f.boxplus(x, dx1), f.boxplus(x, dx2))
-        assert np.linalg.norm(d) <= np.linalg.norm(d - dx2)
-        assert np.linalg.norm(d) <= np.linalg.norm(dx1 - dx2) + 1e-9
+    prop.check_manifold(OracleAdapter, N)
 
 
-def _f_tilde(f, x_tilde, x_hat, u, dt):
-    # jac_test.cpp:283-304
-    x = f.boxplus(x_hat, x_tilde)
-    dx, _, _ = f.dynamics(x, u)
-    dx_hat, _, _ = f.dynamics(x_hat, u)
-    x_plus, x_minus = f.boxplus(x, dx * dt), f.boxplus(x, -dx * dt)
-    xh_plus, xh_minus = f.boxplus(x_hat, dx_hat * dt), f.boxplus(x_hat, -dx_hat * dt)
-    return (f.boxminus(x_plus, xh_plus) - f.boxminus(x_minus, xh_minus)) / (2 * dt)
-
-
-def _blocks(N):
-    b = {"dxPOS": (0, 3), "dxVEL": (3, 3), "dxATT": (6, 3), "dxB_A": (9, 3), "dxB_G": (12, 3), "dxMU": (15, 1),
-         "uA": (0, 3), "uG": (3, 3)}
-    for i in range(N):
-        b["dxZETA_%d" % i] = (16 + 3 * i, 2)
-        b["dxRHO_%d" % i] = (16 + 3 * i + 2, 1)
-    return b  # jac_test.cpp:62-78
-
-
-def _check_block(b, rk, ck, a, fd, tol):
-    r0, rn = b[rk]
-    c0, cn = b[ck]
-    err = np.abs(a[r0:r0 + rn, c0:c0 + cn] - fd[r0:r0 + rn, c0:c0 + cn])
-    assert (err <= tol).all(), "Jacobian block (%s,%s) err %g" % (rk, ck, err.max())
-
-
-@pytest.mark.parametrize("N", NS)
+@pytest.mark.parametrize("N", prop.NS)
 def test_dfdx(N):
-    b = _blocks(N)
-    eps, dt = 1e-5, 1e-3
-    for j in range(NUM_ITERS):
-        p, pix, dep, u = jac_fixture(N, 2000 + j)
-        f = make_oracle(N, p, pix, dep)
-        x_hat = f.x.copy()
-        _, a_dfdx, _ = f.dynamics(x_hat, u)
-        r = np.random.default_rng(77 + j)
-        dx_tilde = _f_tilde(f, r.uniform(-1, 1, f.n) * eps, x_hat, u, dt)
-        d = np.zeros((f.n, f.n))
-        I = np.eye(f.n)
-        for i in range(f.n):
-            # the reference perturbs around dx_tilde (:332-333), restated as is
-            d[:, i] = (_f_tilde(f, dx_tilde + I[:, i] * eps, x_hat, u, dt)
-                       - _f_tilde(f, dx_tilde - I[:, i] * eps, x_hat, u, dt)) / (2 * eps)
-        for rk, ck in [("dxPOS", "dxVEL"), ("dxPOS", "dxATT"), ("dxVEL", "dxVEL"), ("dxVEL", "dxATT"),
-                       ("dxVEL", "dxB_A"), ("dxVEL", "dxB_G"), ("dxVEL", "dxMU"), ("dxATT", "dxATT"),
-                       ("dxATT", "dxB_G")]:
-            _check_block(b, rk, ck, a_dfdx, d, 1e-2)
-        for i in range(N):
-            zk, rk = "dxZETA_%d" % i, "dxRHO_%d" % i
-            for pair in [(zk, "dxVEL"), (zk, "dxB_G"), (zk, zk), (zk, rk), (rk, "dxVEL"), (rk, "dxB_G"), (rk, zk),
-                         (rk, rk)]:
-                _check_block(b, pair[0], pair[1], a_dfdx, d, 5e-1)
+    prop.check_dfdx(OracleAdapter, N)
 
 
-@pytest.mark.parametrize("N", NS)
+@pytest.mark.parametrize("N", prop.NS)
 def test_dfdu(N):
-    b = _blocks(N)
-    eps, dt = 1e-5, 1e-3
-    for j in range(NUM_ITERS):
-        p, pix, dep, u = jac_fixture(N, 3000 + j)
-        f = make_oracle(N, p, pix, dep)
-        x_hat = f.x.copy()
-        _, _, a_dfdu = f.dynamics(x_hat, u)
-        Iu = np.zeros((f.n, 6))
-        Iu[orc.dxB_A:orc.dxB_A + 6, :] = np.eye(6)
-        r = np.random.default_rng(99 + j)
-        dx_tilde = _f_tilde(f, r.uniform(-1, 1, f.n) * eps, x_hat, u, dt)
-        d = np.zeros((f.n, 6))
-        for i in range(6):
-            d[:, i] = (_f_tilde(f, dx_tilde + Iu[:, i] * eps, x_hat, u, dt)
-                       - _f_tilde(f, dx_tilde - Iu[:, i] * eps, x_hat, u, dt)) / (2 * eps)
-        for rk, ck in [("dxVEL", "uA"), ("dxVEL", "uG"), ("dxATT", "uG")]:
-            _check_block(b, rk, ck, a_dfdu, d, 1e-2)
-        for i in range(N):
-            _check_block(b, "dxZETA_%d" % i, "uG", a_dfdu, d, 5e-1)
-            _check_block(b, "dxRHO_%d" % i, "uG", a_dfdu, d, 5e-1)
+    prop.check_dfdu(OracleAdapter, N)
 
 
-def _htest(f, mtype, id, dim, tol=1e-3):
-    # jac_test.cpp:172-226
-    x0 = f.x.copy()
-    z0, H = f.h(mtype, x0, id)
-    a = H[:dim, :]
-    d = np.zeros((dim, f.n))
-    eps = 1e-6
-    I = np.eye(f.n)
-    for i in range(f.n):
-        xp = f.boxplus(x0, I[:, i] * eps)
-        zp, _ = f.h(mtype, xp, id)
-        if mtype == orc.QZETA:
-            d[:, i] = orc.q_feat_boxminus(zp, z0) / eps
-        elif mtype == orc.ATT:
-            d[:, i] = orc.q_boxminus(zp, z0) / eps
-        else:
-            d[:, i] = (zp[:dim] - z0[:dim]) / eps
-    thr = max(tol * np.linalg.norm(a), tol)
-    assert (np.abs(a - d) <= thr).all(), "h type %d id %d err %g thr %g" % (mtype, id, np.abs(a - d).max(), thr)
-
-
-@pytest.mark.parametrize("N", NS)
+@pytest.mark.parametrize("N", prop.NS)
 def test_h(N):
-    for j in range(NUM_ITERS):
-        p, pix, dep, _ = jac_fixture(N, 4000 + j)
-        f = make_oracle(N, p, pix, dep)
-        _htest(f, orc.ACC, 0, 2)
-        _htest(f, orc.POS, 0, 3)
-        _htest(f, orc.VEL, 0, 3)
-        _htest(f, orc.ALT, 0, 1)
-        f.set_drag_term(True)
-        _htest(f, orc.ATT, 0, 3)
-        f.set_drag_term(False)
-        _htest(f, orc.ATT, 0, 3)
-        _htest(f, orc.ACC, 0, 3)  # gravity form of h_acc (not exercised by the reference test)
-        for i in range(f.len_features):
-            _htest(f, orc.FEAT, i, 2, 1e-1)
-            _htest(f, orc.QZETA, i, 2)
-            _htest(f, orc.DEPTH, i, 1)
-            _htest(f, orc.INV_DEPTH, i, 1)
-
-
-def _euler(q):
-    w, x, y, z = q
-    return (np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), np.arcsin(2 * (w * y - z * x)),
-            np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z)))
+    prop.check_h(OracleAdapter, N)
 
 
 @pytest.mark.parametrize("N", [3])
 def test_kf_reset(N):
-    # jac_test.cpp:446-487
-    for j in range(NUM_ITERS):
-        p, pix, dep, _ = jac_fixture(N, 6000 + j)
-        f = make_oracle(N, p, pix, dep)
-        xm = f.x.copy()
-        g = f.clone()
-        g.keyframe_reset()
-        xp = g.x.copy()
-        a = g.A.copy()
-        rm, pm, _ = _euler(xm[6:10])
-        rp, pp, yp = _euler(xp[6:10])
-        assert abs(rm - rp) < 1e-8 and abs(pm - pp) < 1e-8 and abs(yp) < 1e-8
-        d = np.zeros((f.n, f.n))
-        eps = 1e-6
-        I = np.eye(f.n)
-        for i in range(f.n):
-            g2 = f.clone()
-            g2.x[:] = f.boxplus(xm, I[:, i] * eps)
-            g2.keyframe_reset()
-            d[:, i] = f.boxminus(g2.x.copy(), xp) / eps
-        assert np.abs(a[0:3, 0:3] - d[0:3, 0:3]).max() <= 1e-3
-        assert np.abs(a[6:9, 6:9] - d[6:9, 6:9]).max() <= 1e-1
-    assert np.abs(a - d).max() <= 1e-1
+    prop.check_kf_reset(OracleAdapter, N)
 
 
 def test_seq_oracle_delayed_measurement_equals_in_order_when_input_is_unrotated():

@@ -19,8 +19,14 @@ def main():
     dev = torch.device("cuda:0")
     sc = scene.make_scene(B, N, 4, seed=3)
     g = v.BatchVIEKF(B, N, sc["params"])
-    if kernel:
+    from vi_ekf_amd import capi
+    if kernel == 3:      # the tile family whatever the batch size
+        g.set_tuning(capi.TUNE_TILES, 2)
+    elif kernel == 4:    # the on-chip families without the tile family
+        g.set_tuning(capi.TUNE_TILES, 0)
+    elif kernel:
         g.set_kernel(kernel)
+    print(g.describe())
     g.use_torch_stream()
     d = {k: torch.tensor(sc[k], device=dev) for k in ("u", "z", "dt", "slot", "R")}
     pix = torch.tensor(np.ascontiguousarray(sc["pix"].transpose(1, 0, 2)), device=dev)
@@ -44,7 +50,7 @@ def main():
         return ms
 
     timeit(lambda: g.propagate(d["u"][0], d["dt"]), "propagate")
-    for M in (1, 2, 10, N):
+    for M in (1, 2, 10, 25, N):
         timeit(lambda: g.update_feat(d["z"][0][:, :M].contiguous(), d["slot"][:, :M].contiguous(), d["R"],
                                      result=res[:, :M].contiguous()), "update_feat M=%d" % M)
     timeit(lambda: g.step(d["u"][0], d["dt"], d["z"][0], d["slot"], d["R"], result=res), "step")

@@ -30,7 +30,10 @@ SYMBOLS = [
     "viekf_seq_disable_logger", "viekf_batch_step_n", "viekf_batch_get_cov_block", "viekf_seq_get_global_pose",
     "viekf_seq_get_global_cov", "viekf_seq_init_feature", "viekf_batch_set_active", "viekf_batch_snapshot_filters",
     "viekf_batch_restore_filters", "viekf_seq_create_independent", "viekf_seq_propagate_t", "viekf_seq_add_measurement_t",
-    "viekf_batch_set_tuning",
+    "viekf_batch_set_tuning", "viekf_batch_set_drag_term", "viekf_batch_get_drag_term", "viekf_batch_eval_jacobians",
+    "viekf_batch_eval_h_jacobian", "viekf_batch_boxplus", "viekf_batch_boxminus", "viekf_batch_eval_reset_jacobian",
+    "viekf_seq_propagate_state", "viekf_seq_set_x0", "viekf_seq_set_imu_bias", "viekf_seq_keyframe_reset",
+    "viekf_seq_get_features", "viekf_seq_get_feat", "viekf_seq_drop_features",
 ]
 
 
@@ -118,6 +121,13 @@ def lib():
         L.viekf_batch_sync.argtypes = [_vp]
         L.viekf_batch_set_kernel.argtypes = [_vp, C.c_int32]
         L.viekf_batch_set_tuning.argtypes = [_vp, C.c_int32, C.c_int32]
+        L.viekf_batch_set_drag_term.argtypes = [_vp, C.c_int32]
+        L.viekf_batch_get_drag_term.argtypes = [_vp, C.POINTER(C.c_int32)]
+        L.viekf_batch_eval_jacobians.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        L.viekf_batch_eval_h_jacobian.argtypes = [_vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int]
+        L.viekf_batch_boxplus.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
+        L.viekf_batch_boxminus.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
+        L.viekf_batch_eval_reset_jacobian.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_get_state.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_set_state.argtypes = [_vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_get_status.argtypes = [_vp, _vp, C.c_int]

@@ -15,6 +15,7 @@
 #include "../../include/viekf.h"
 #include "viekf_host.hpp"
 #include "viekf_instances.hpp"
+#include "viekf_kernels_hooks.hpp"
 
 // (the fused-step kernels are compiled in viekf_inst.hip, one object file per group of instances)
 #define RES_EXT(RB, NW, NS) VIEKF_RES_FLAVOURS(extern, RB, NW, NS)
@@ -1142,6 +1143,125 @@ int viekf_batch_eval_h(viekf_batch* b, int32_t type, const int32_t* slot, double
   HIP_TRY(hipGetLastError());
   if (where == VIEKF_HOST) {
     HIP_TRY(hipMemcpyAsync(zhat, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+// ---- run-time drag switch (VIEKF::set_drag_term / get_drag_term, include/vi_ekf.h:290-291) ----
+int viekf_batch_set_drag_term(viekf_batch* b, int32_t use_drag_term) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  b->params.use_drag_term = use_drag_term != 0;
+  b->dp.use_drag_term = use_drag_term != 0;
+  // (every kernel reads the flag from the device-resident parameter block at launch: ordered on the batch's stream)
+  HIP_TRY(hipMemcpyAsync(b->d_dp, &b->dp, sizeof(DevParams), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));   // (b->dp is pageable host memory: the copy has read it when this returns)
+  return VIEKF_OK;
+}
+int viekf_batch_get_drag_term(const viekf_batch* b, int32_t* use_drag_term) {
+  if (!b || !use_drag_term) return fail(VIEKF_ERR_INVALID, "null argument");
+  *use_drag_term = b->params.use_drag_term;
+  return VIEKF_OK;
+}
+
+// ---- the reference's public test hooks, evaluated on the device (viekf_kernels_hooks.hpp) ----
+int viekf_batch_eval_jacobians(viekf_batch* b, const double* x, const double* u, double* xdot, double* A, double* G, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || (!xdot && !A && !G)) return fail(VIEKF_ERR_INVALID, "u and at least one output must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B, n = (size_t)b->n;
+  const size_t xb = sizeof(double) * B * b->nx, ub = sizeof(double) * 6 * B, db = sizeof(double) * B * n, Ab = sizeof(double) * B * n * n,
+               Gb = sizeof(double) * B * n * 6;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(xb) + stage_size(ub) + stage_size(db) + stage_size(Ab) + stage_size(Gb))) return rc;
+  const double *d_x = nullptr, *d_u = nullptr;
+  if (int rc = in_ptr(b, x, B * b->nx, where, &d_x)) return rc;
+  if (int rc = in_ptr(b, u, 6 * B, where, &d_u)) return rc;
+  auto outp = [&](double* p, size_t bytes) { return !p ? (double*)nullptr : (where == VIEKF_DEVICE ? p : static_cast<double*>(stage_take(b, bytes))); };
+  double *d_xd = outp(xdot, db), *d_A = outp(A, Ab), *d_G = outp(G, Gb);
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_eval_jacobians, dim3(b->B), dim3(256), 0, b->stream, a, d_x, d_u, d_xd, d_A, d_G);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (xdot) HIP_TRY(hipMemcpyAsync(xdot, d_xd, db, hipMemcpyDeviceToHost, b->stream));
+    if (A) HIP_TRY(hipMemcpyAsync(A, d_A, Ab, hipMemcpyDeviceToHost, b->stream));
+    if (G) HIP_TRY(hipMemcpyAsync(G, d_G, Gb, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+int viekf_batch_eval_h_jacobian(viekf_batch* b, const double* x, int32_t type, const int32_t* slot, double* zhat, double* H, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!zhat || !H) return fail(VIEKF_ERR_INVALID, "zhat / H is null");
+  if (type < 0 || type > 9 || type == 7) return fail(VIEKF_ERR_INVALID, "no measurement model for this type");
+  const bool needs_slot = type == 5 || type == 6 || type == 8 || type == 9;
+  if (needs_slot && !slot) return fail(VIEKF_ERR_INVALID, "this measurement model needs a feature slot");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B;
+  const size_t xb = sizeof(double) * B * b->nx, sb = sizeof(int32_t) * B, zb = sizeof(double) * 4 * B, Hb = sizeof(double) * 3 * B * b->n;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(xb) + stage_size(sb) + stage_size(zb) + stage_size(Hb))) return rc;
+  const double* d_x = nullptr;
+  const int32_t* d_slot = nullptr;
+  if (int rc = in_ptr(b, x, B * b->nx, where, &d_x)) return rc;
+  if (needs_slot)
+    if (int rc = in_ptr(b, slot, B, where, &d_slot)) return rc;
+  double* d_z = where == VIEKF_DEVICE ? zhat : static_cast<double*>(stage_take(b, zb));
+  double* d_H = where == VIEKF_DEVICE ? H : static_cast<double*>(stage_take(b, Hb));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_eval_H, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, a, d_x, type, d_slot, d_z, d_H);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(zhat, d_z, zb, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(H, d_H, Hb, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+
+static int boxop(viekf_batch* b, int minus, const double* x1, const double* v, double* out, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!x1 || !v || !out) return fail(VIEKF_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B, xb = sizeof(double) * B * b->nx, db = sizeof(double) * B * b->n;
+  const size_t vb = minus ? xb : db, ob = minus ? db : xb;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(xb) + stage_size(vb) + stage_size(ob))) return rc;
+  const double *d_x1 = nullptr, *d_v = nullptr;
+  if (int rc = in_ptr(b, x1, xb / sizeof(double), where, &d_x1)) return rc;
+  if (int rc = in_ptr(b, v, vb / sizeof(double), where, &d_v)) return rc;
+  double* d_o = where == VIEKF_DEVICE ? out : static_cast<double*>(stage_take(b, ob));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_boxops, dim3(b->B), dim3(64), 0, b->stream, a, minus, d_x1, d_v, d_o);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    HIP_TRY(hipMemcpyAsync(out, d_o, ob, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_boxplus(viekf_batch* b, const double* x, const double* dx, double* out, viekf_mem where) { return boxop(b, 0, x, dx, out, where); }
+int viekf_batch_boxminus(viekf_batch* b, const double* x1, const double* x2, double* out, viekf_mem where) { return boxop(b, 1, x1, x2, out, where); }
+
+int viekf_batch_eval_reset_jacobian(viekf_batch* b, const double* xm, double* xp, double* N, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!xm || (!xp && !N)) return fail(VIEKF_ERR_INVALID, "xm and at least one output must not be null");
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B, xb = sizeof(double) * B * b->nx, Nb = sizeof(double) * B * b->n * b->n;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, 2 * stage_size(xb) + stage_size(Nb))) return rc;
+  const double* d_xm = nullptr;
+  if (int rc = in_ptr(b, xm, xb / sizeof(double), where, &d_xm)) return rc;
+  double* d_xp = !xp ? nullptr : (where == VIEKF_DEVICE ? xp : static_cast<double*>(stage_take(b, xb)));
+  double* d_N = !N ? nullptr : (where == VIEKF_DEVICE ? N : static_cast<double*>(stage_take(b, Nb)));
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_eval_reset, dim3(b->B), dim3(256), 0, b->stream, a, d_xm, d_xp, d_N);
+  HIP_TRY(hipGetLastError());
+  if (where == VIEKF_HOST) {
+    if (xp) HIP_TRY(hipMemcpyAsync(xp, d_xp, xb, hipMemcpyDeviceToHost, b->stream));
+    if (N) HIP_TRY(hipMemcpyAsync(N, d_N, Nb, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
   }
   return VIEKF_OK;

@@ -1195,6 +1195,41 @@ __global__ void k_cov_block(StreamArgs a, int r0, int c0, int nr, int nc, double
 }
 #endif
 
+// The reference's measurement models (src/vi_ekf/vi_ekf_meas.cpp:281-386): zhat = h(x) and the non-zero columns of H -- at most six
+// (`cols`, their number `nc`), Hc [3][6] row-major = the entries of H in those columns.  One lane; xs = the filter's state.
+__device__ __forceinline__ void meas_model(int type, const double* xs, int slot, const DevParams& prm, double* zhat, int* cols,
+                                           double* Hc, int& nc) {
+  nc = 0;
+  for (int i = 0; i < 18; i++) Hc[i] = 0.0;
+  auto col = [&](int c) { cols[nc] = c; return nc++; };
+  if (type == MT_ACC) {                                       // vi_ekf_meas.cpp:281-306
+    if (prm.use_drag_term) {
+      const double mu = xs[xMU];
+      zhat[0] = -mu * xs[xVEL] + xs[xB_A]; zhat[1] = -mu * xs[xVEL + 1] + xs[xB_A + 1];
+      int c;
+      c = col(dxVEL); Hc[0 * 6 + c] = -mu;  c = col(dxVEL + 1); Hc[1 * 6 + c] = -mu;
+      c = col(dxB_A); Hc[0 * 6 + c] = 1.0;  c = col(dxB_A + 1); Hc[1 * 6 + c] = 1.0;
+      c = col(dxMU); Hc[0 * 6 + c] = -xs[xVEL]; Hc[1 * 6 + c] = -xs[xVEL + 1];
+    } else {
+      const double g[3] = {0.0, 0.0, kGravity}; double gB[3], ng[3], Sk[9];
+      q_rotp(xs + xATT, g, gB);
+      for (int i = 0; i < 3; i++) { zhat[i] = xs[xB_A + i] - gB[i]; ng[i] = -1.0 * gB[i]; }
+      skew3(ng, Sk);
+      for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); for (int i = 0; i < 3; i++) Hc[i * 6 + c] = Sk[i * 3 + j]; }
+      for (int j = 0; j < 3; j++) { const int c = col(dxB_A + j); Hc[j * 6 + c] = 1.0; }
+    }
+  } else if (type == MT_ALT) { zhat[0] = -xs[xPOS + 2]; const int c = col(dxPOS + 2); Hc[c] = -1.0; }
+  else if (type == MT_ATT) { for (int i = 0; i < 4; i++) zhat[i] = xs[xATT + i]; for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); Hc[j * 6 + c] = 1.0; } }
+  else if (type == MT_POS) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xPOS + j]; const int c = col(dxPOS + j); Hc[j * 6 + c] = 1.0; } }
+  else if (type == MT_VEL) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xVEL + j]; const int c = col(dxVEL + j); Hc[j * 6 + c] = 1.0; } }
+  else if (type == MT_QZETA) { for (int i = 0; i < 4; i++) zhat[i] = xs[xZ + 5 * slot + i]; for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[j * 6 + c] = 1.0; } }
+  else if (type == MT_FEAT) {
+    double Hb[4]; h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
+    for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[0 * 6 + c] = Hb[0 * 2 + j]; Hc[1 * 6 + c] = Hb[1 * 2 + j]; }
+  } else if (type == MT_DEPTH) { const double rho = xs[xZ + 5 * slot + 4]; zhat[0] = 1.0 / rho; const int c = col(dxZ + 3 * slot + 2); Hc[c] = -1.0 / (rho * rho); }
+  else if (type == MT_INV_DEPTH) { zhat[0] = xs[xZ + 5 * slot + 4]; const int c = col(dxZ + 3 * slot + 2); Hc[c] = 1.0; }
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, int zdim, int rdim,
                                                       const double* __restrict__ z_all, const int* __restrict__ slot_all,
@@ -1234,34 +1269,7 @@ __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, in
 
   if (tid == 0) {   // measurement model: zhat, the non-zero columns of H, residual
     int cols[6]; double Hc[18]; int nc = 0; double zhat[4] = {0, 0, 0, 0}; double r3[3] = {0, 0, 0};
-    for (int i = 0; i < 18; i++) Hc[i] = 0.0;
-    auto col = [&](int c) { cols[nc] = c; return nc++; };
-    if (type == MT_ACC) {                                       // vi_ekf_meas.cpp:281-306
-      if (prm.use_drag_term) {
-        const double mu = xs[xMU];
-        zhat[0] = -mu * xs[xVEL] + xs[xB_A]; zhat[1] = -mu * xs[xVEL + 1] + xs[xB_A + 1];
-        int c;
-        c = col(dxVEL); Hc[0 * 6 + c] = -mu;  c = col(dxVEL + 1); Hc[1 * 6 + c] = -mu;
-        c = col(dxB_A); Hc[0 * 6 + c] = 1.0;  c = col(dxB_A + 1); Hc[1 * 6 + c] = 1.0;
-        c = col(dxMU); Hc[0 * 6 + c] = -xs[xVEL]; Hc[1 * 6 + c] = -xs[xVEL + 1];
-      } else {
-        const double g[3] = {0.0, 0.0, kGravity}; double gB[3], ng[3], Sk[9];
-        q_rotp(xs + xATT, g, gB);
-        for (int i = 0; i < 3; i++) { zhat[i] = xs[xB_A + i] - gB[i]; ng[i] = -1.0 * gB[i]; }
-        skew3(ng, Sk);
-        for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); for (int i = 0; i < 3; i++) Hc[i * 6 + c] = Sk[i * 3 + j]; }
-        for (int j = 0; j < 3; j++) { const int c = col(dxB_A + j); Hc[j * 6 + c] = 1.0; }
-      }
-    } else if (type == MT_ALT) { zhat[0] = -xs[xPOS + 2]; const int c = col(dxPOS + 2); Hc[c] = -1.0; }
-    else if (type == MT_ATT) { for (int i = 0; i < 4; i++) zhat[i] = xs[xATT + i]; for (int j = 0; j < 3; j++) { const int c = col(dxATT + j); Hc[j * 6 + c] = 1.0; } }
-    else if (type == MT_POS) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xPOS + j]; const int c = col(dxPOS + j); Hc[j * 6 + c] = 1.0; } }
-    else if (type == MT_VEL) { for (int j = 0; j < 3; j++) { zhat[j] = xs[xVEL + j]; const int c = col(dxVEL + j); Hc[j * 6 + c] = 1.0; } }
-    else if (type == MT_QZETA) { for (int i = 0; i < 4; i++) zhat[i] = xs[xZ + 5 * slot + i]; for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[j * 6 + c] = 1.0; } }
-    else if (type == MT_FEAT) {
-      double Hb[4]; h_feat(xs + xZ + 5 * slot, prm, zhat, Hb);
-      for (int j = 0; j < 2; j++) { const int c = col(dxZ + 3 * slot + j); Hc[0 * 6 + c] = Hb[0 * 2 + j]; Hc[1 * 6 + c] = Hb[1 * 2 + j]; }
-    } else if (type == MT_DEPTH) { const double rho = xs[xZ + 5 * slot + 4]; zhat[0] = 1.0 / rho; const int c = col(dxZ + 3 * slot + 2); Hc[c] = -1.0 / (rho * rho); }
-    else if (type == MT_INV_DEPTH) { zhat[0] = xs[xZ + 5 * slot + 4]; const int c = col(dxZ + 3 * slot + 2); Hc[c] = 1.0; }
+    meas_model(type, xs, slot, prm, zhat, cols, Hc, nc);
     if (type == MT_QZETA) q_feat_boxminus_dev(z, zhat, r3);           // :210-213
     else if (type == MT_ATT) q_boxminus_dev(z, zhat, r3);             // :214-217
     else for (int i = 0; i < zdim && i < 3; i++) r3[i] = z[i] - zhat[i];

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <string>
 #include <utility>
@@ -389,6 +390,29 @@ void plan_handle(viekf_seq* s, int b, std::vector<SeqOp>& ops) {
   prop(f.u[ui].second, f.u[ui].first);                             // :118
   while ((int)f.zbuf.size() > s->MH) f.zbuf.pop_back();            // :121-122
   while ((int)f.u.size() > s->H) f.u.pop_back();                   // :125-126
+}
+
+// VIEKF::keyframe_reset(), src/vi_ekf/vi_ekf_kfr.cpp:56-157, for the filters with reset[b] != 0: the device resets state and
+// covariance and hands back the edge; the node frame moves here (:147-150).  edges [B][17] may be NULL.
+int reset_and_move_node(viekf_seq* s, const std::vector<uint8_t>& reset, double* edges) {
+  const int B = s->B;
+  std::vector<double> eb((size_t)B * 17, 0.0);
+  if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), eb.data(), VIEKF_HOST)) return rc;
+  for (int b = 0; b < B; b++) {
+    if (!reset[b]) continue;
+    const double* e = eb.data() + 17 * (size_t)b;                // {t(3), q_yaw(4), cov_pos(9), cov_yaw}
+    double C[36] = {};                                           // edge.cov: position block and the yaw variance (:59-63,126)
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) C[r + 6 * c] = e[7 + r + 3 * c];
+    C[5 + 6 * 5] = e[16];
+    double* nd = s->node.data() + 7 * (size_t)b;
+    add_adj_cov(nd, C, s->node_cov.data() + 36 * (size_t)b);      // :149 (with the node pose BEFORE it moves)
+    double nn[7];
+    xform_compose(nd, e, nn);                                    // :150
+    std::memcpy(nd, nn, sizeof nn);
+  }
+  if (edges) std::memcpy(edges, eb.data(), sizeof(double) * 17 * (size_t)B);
+  return VIEKF_OK;
 }
 
 // independent clocks: the reference changes x_[i_], P_[i_] in place (updates, init_feature, clear_feature, keyframe reset), and
@@ -808,12 +832,12 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
   return finish();
 }
 
-int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count, uint8_t* did_reset, double* edges) {
+static int keep_features_impl(viekf_seq* s, const int32_t* ids, int32_t count, bool kf_test, uint8_t* did_reset, double* edges) {
   if (!s || (count > 0 && !ids) || count < 0) return VIEKF_ERR_INVALID;
   const int B = s->B, N = s->N;
   std::vector<uint8_t> keep((size_t)B * N, 0), reset(B, 0);
   bool any_drop = false, any_reset = false;
-  const bool use_kf = s->prm.use_keyframe_reset != 0;
+  const bool use_kf = kf_test && s->prm.use_keyframe_reset != 0;
   for (int b = 0; b < B; b++) {
     std::vector<int32_t> want;
     for (int k = 0; k < count; k++)
@@ -844,29 +868,114 @@ int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count
     if (int rc = viekf_batch_keep_features(s->core, keep.data(), nullptr, VIEKF_HOST)) return rc;
     }
   if (edges) std::memset(edges, 0, sizeof(double) * 17 * (size_t)B);
-  if (any_reset) {
-    std::vector<double> eb((size_t)B * 17, 0.0);
-    if (int rc = viekf_batch_keyframe_reset(s->core, reset.data(), eb.data(), VIEKF_HOST)) return rc;
-    for (int b = 0; b < B; b++) {
-      if (!reset[b]) continue;
-      const double* e = eb.data() + 17 * (size_t)b;                // {t(3), q_yaw(4), cov_pos(9), cov_yaw}
-      double C[36] = {};                                           // edge.cov: position block and the yaw variance (:59-63,126)
-      for (int c = 0; c < 3; c++)
-        for (int r = 0; r < 3; r++) C[r + 6 * c] = e[7 + r + 3 * c];
-      C[5 + 6 * 5] = e[16];
-      double* nd = s->node.data() + 7 * (size_t)b;
-      add_adj_cov(nd, C, s->node_cov.data() + 36 * (size_t)b);      // :149 (with the node pose BEFORE it moves)
-      double nn[7];
-      xform_compose(nd, e, nn);                                    // :150
-      std::memcpy(nd, nn, sizeof nn);
-    }
-    if (edges) std::memcpy(edges, eb.data(), sizeof(double) * 17 * (size_t)B);
-  }
+  if (any_reset)
+    if (int rc = reset_and_move_node(s, reset, edges)) return rc;
   if (s->indep && (any_drop || any_reset)) {
     std::vector<uint8_t> all(B, 1);
     if (int rc = refresh_slots(s, all)) return rc;
   }
   if (did_reset) std::memcpy(did_reset, reset.data(), B);
+  return VIEKF_OK;
+}
+
+int viekf_seq_keep_only_features(viekf_seq* s, const int32_t* ids, int32_t count, uint8_t* did_reset, double* edges) {
+  return keep_features_impl(s, ids, count, true, did_reset, edges);
+}
+// VIEKF::clear_feature (src/vi_ekf/vi_ekf_feat.cpp:50-73) for every tracked feature NOT listed: the removal of keep_only_features
+// without its keyframe-overlap test (:119-139 belongs to keep_only_features alone)
+int viekf_seq_drop_features(viekf_seq* s, const int32_t* keep_ids, int32_t count) {
+  return keep_features_impl(s, keep_ids, count, false, nullptr, nullptr);
+}
+
+// VIEKF::propagate_state(u, t, save_input), src/vi_ekf/vi_ekf.cpp:262-318, with the flag the reference's own replay uses
+int viekf_seq_propagate_state(viekf_seq* s, const double* u, double t, int32_t save_input) {
+  if (!s || !u) return VIEKF_ERR_INVALID;
+  if (save_input) return viekf_seq_propagate(s, u, t);
+  if (s->indep) return VIEKF_ERR_UNSUPPORTED;   // (independent clocks: inputs are always recorded, per filter)
+  return propagate_core(s, u, t, false);
+}
+
+namespace {
+// x_[i_] of every filter, edited in place on the host (set_x0 / set_imu_bias are start-up calls): one read, one write
+int edit_live_state(viekf_seq* s, const std::function<void(int, double*)>& f) {
+  const int nx = 17 + 5 * s->N;
+  std::vector<double> x((size_t)s->B * nx);
+  if (int rc = viekf_batch_get_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  for (int b = 0; b < s->B; b++) f(b, x.data() + (size_t)b * nx);
+  if (int rc = viekf_batch_set_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  if (s->indep) { std::vector<uint8_t> all(s->B, 1); return refresh_slots(s, all); }
+  return VIEKF_OK;
+}
+}  // namespace
+
+int viekf_seq_set_x0(viekf_seq* s, const double* x0) {            // VIEKF::set_x0, vi_ekf.cpp:157-160: x_[i_].topRows(xZ) = x0
+  if (!s || !x0) return VIEKF_ERR_INVALID;
+  return edit_live_state(s, [&](int b, double* x) { std::memcpy(x, x0 + 17 * (size_t)b, sizeof(double) * 17); });
+}
+
+int viekf_seq_set_imu_bias(viekf_seq* s, const double* b_g, const double* b_a) {   // VIEKF::set_imu_bias, vi_ekf.cpp:179-183
+  if (!s || !b_g || !b_a) return VIEKF_ERR_INVALID;
+  return edit_live_state(s, [&](int b, double* x) {
+    for (int i = 0; i < 3; i++) { x[13 + i] = b_g[3 * (size_t)b + i]; x[10 + i] = b_a[3 * (size_t)b + i]; }
+  });
+}
+
+int viekf_seq_keyframe_reset(viekf_seq* s, const uint8_t* mask, double* edges) {   // VIEKF::keyframe_reset(), vi_ekf_kfr.cpp:56-157
+  if (!s) return VIEKF_ERR_INVALID;
+  std::vector<uint8_t> reset(s->B, 1);
+  if (mask) reset.assign(mask, mask + s->B);
+  if (edges) std::memset(edges, 0, sizeof(double) * 17 * (size_t)s->B);
+  if (int rc = reset_and_move_node(s, reset, edges)) return rc;
+  if (s->indep) return refresh_slots(s, reset);
+  return VIEKF_OK;
+}
+
+// get_depths / get_zetas / get_qzetas / get_zeta (vi_ekf.cpp:210-246): per feature slot 1 / rho, zeta = q_zeta.rota(e_z), q_zeta;
+// slots past a filter's len_features: NaN.  Any output may be NULL.
+int viekf_seq_get_features(viekf_seq* s, double* depths, double* zetas, double* qzetas) {
+  if (!s) return VIEKF_ERR_INVALID;
+  const int nx = 17 + 5 * s->N, N = s->N;
+  std::vector<double> x((size_t)s->B * nx);
+  if (int rc = viekf_batch_get_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  const double ez[3] = {0.0, 0.0, 1.0};
+  for (int b = 0; b < s->B; b++)
+    for (int i = 0; i < N; i++) {
+      const double* f = x.data() + (size_t)b * nx + 17 + 5 * i;
+      const bool on = i < (int)s->ids[b].size();
+      if (depths) depths[(size_t)b * N + i] = on ? 1.0 / f[4] : NAN;
+      if (zetas) {
+        double z[3] = {NAN, NAN, NAN};
+        if (on) rota(f, ez, z);
+        std::memcpy(zetas + ((size_t)b * N + i) * 3, z, sizeof z);
+      }
+      if (qzetas)
+        for (int k = 0; k < 4; k++) qzetas[((size_t)b * N + i) * 4 + k] = on ? f[k] : NAN;
+    }
+  return VIEKF_OK;
+}
+
+// get_feat(id) / get_depth(id) (vi_ekf.cpp:248-260) by GLOBAL feature id per filter: pix [B][2] = cam_F zeta / zeta_z + cam_center,
+// depth [B] = 1 / rho; an id the filter does not track: NaN (the reference indexes with -1 there).  Either output may be NULL.
+int viekf_seq_get_feat(viekf_seq* s, const int32_t* id, double* pix, double* depth) {
+  if (!s || !id) return VIEKF_ERR_INVALID;
+  const int nx = 17 + 5 * s->N;
+  std::vector<double> x((size_t)s->B * nx);
+  if (int rc = viekf_batch_get_state(s->core, x.data(), nullptr, nullptr, VIEKF_HOST)) return rc;
+  const double ez[3] = {0.0, 0.0, 1.0};
+  for (int b = 0; b < s->B; b++) {
+    const int i = local_id(s, b, id[b]);
+    double px[2] = {NAN, NAN}, d = NAN;
+    if (i >= 0) {
+      const double* f = x.data() + (size_t)b * nx + 17 + 5 * i;
+      double z[3];
+      rota(f, ez, z);
+      px[0] = s->prm.focal_len[0] * z[0] / z[2] + s->prm.cam_center[0];
+      px[1] = s->prm.focal_len[1] * z[1] / z[2] + s->prm.cam_center[1];
+      d = 1.0 / f[4];
+    }
+    if (pix) { pix[2 * (size_t)b] = px[0]; pix[2 * (size_t)b + 1] = px[1]; }
+    if (depth) depth[b] = d;
+  }
   return VIEKF_OK;
 }
 

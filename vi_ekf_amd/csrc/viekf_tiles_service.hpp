@@ -23,6 +23,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
   int par = 0;
   __builtin_amdgcn_s_setprio(3);   // the per-update critical path runs on this wave
   double dt = sm[42];
+  RES_STAMP(S, lane == 0, 0);
   // dynamics of propagate kp (of S.kp): body Jacobian on lane 0 (+ A_v G_b for the workers' expansion of the feature rows), then
   // one feature per lane -- before B0, while the worker waves are still loading P from HBM
   auto dyn_body = [&](int kp) {
@@ -43,7 +44,9 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     for (int f = lane; f < N; f += 64) res_feature_phase(f, len, dtk, xs, S.ctx, S.Z, S.phiff);
   };
   if (S.do_prop) { dyn_body(0); dyn_feat(dt); }
+  RES_STAMP(S, lane == 0, 14);
   __syncthreads();  // B0
+  RES_STAMP(S, lane == 0, 1);
 
   const int nkp = MP ? S.kp : 1;
   if (S.do_prop) {
@@ -79,6 +82,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     }
     __syncthreads();  // B4q
   }
+  RES_STAMP(S, lane == 0, 2);
 
   // lane roles for the state correction (one instruction stream, no divergence):
   //   lane f < N           : feature f  -> rows 16+3f..+2 : bearing quaternion (2 rows) + inverse depth (1 row)
@@ -107,6 +111,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
 
   int m = __builtin_amdgcn_readfirstlane(res_next_valid(S, 0));
   __syncthreads();  // Bp : the workers published Pd (zeta blocks) and the first measurement's columns
+  RES_STAMP(S, lane == 0, 3);
   double pf00 = 0.0, pf01 = 0.0, pf11 = 0.0;
   if (isfeat) { const double* pd = S.Pd + 4 * fid; pf00 = pd[0]; pf01 = pd[1]; pf11 = pd[3]; }
   // Uniform per-measurement values, computed by the lane of the measured feature and handed to the whole wave with v_readlane
@@ -161,7 +166,9 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     publish(cur, 0);
   }
   int2 sq = S.mseq[min(m, S.mcap - 1)];
+  RES_STAMP(S, lane == 0, 4);
   __syncthreads();  // B1
+  RES_STAMP(S, lane == 0, 5);
   int cnt = 0;
 
   while (m < M) {
@@ -169,6 +176,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     sq = S.mseq[min(mnext, S.mcap - 1)];
     const double* Cc = S.Cb + (cnt & 1) * 2 * NQ;
     const double2 c0 = lds_ld2(Cc + 2 * q0), c1 = lds_ld2(Cc + 2 * q1), c2 = lds_ld2(Cc + 2 * q2);
+    RES_STAMP(S, lane == 0 && cnt < 8, 16 + 4 * cnt + 0);
     const bool gated = cur.skip == 1.0;
     // NaN guard (vi_ekf_meas.cpp:247: a NaN in K or H skips the update, not fix_depth): K = C Hb^T S^-1 has one iff the column
     // pair or the measurement's 2x2 factors have one -- the worker threads test every row of the pair where they form it
@@ -202,6 +210,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
       pf01 = fma(-L01, fma(k01, c1.y, k00 * c1.x), pf01);
       pf11 = fma(-L11, fma(k11, c1.y, k10 * c1.x), pf11);
     }
+    RES_STAMP(S, lane == 0 && cnt < 8, 16 + 4 * cnt + 1);
     if (lane == 0) sm[40 + par] = 0.0;
     // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238): almost never fires -- one wave-wide test
     const bool odd_depth = !gated && isfeat && fid < len && !(lin >= 0.0 && lin <= 1e2);
@@ -228,13 +237,16 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
       publish(nxt, (cnt + 1) & 1);
     }
     if (result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
+    RES_STAMP(S, lane == 0 && cnt < 8, 16 + 4 * cnt + 2);
     cur = nxt;
     par ^= 1;
     cnt++;
     __syncthreads();  // B1 (the only barrier of an update)
+    RES_STAMP(S, lane == 0 && cnt <= 8, 16 + 4 * (cnt - 1) + 3);
     m = mnext;
   }
 
+  RES_STAMP(S, lane == 0, 12);
   if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
   if (haslin) *linptr = lin;
   wave_lds_sync();   // (the lanes below read what other lanes of this wave just wrote)
@@ -248,6 +260,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     xg[i] = v;
   }
   if (flag) atomicOr(&a.flags[S.b], flag);
+  RES_STAMP(S, lane == 0, 13);
 }
 
 }  // namespace viekf

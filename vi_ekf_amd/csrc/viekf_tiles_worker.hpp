@@ -90,6 +90,9 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     Pbb[r * 16 + c] = P[max(r, c) + (long)min(r, c) * ld];
   }
   int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  const bool st0 = (W == 0) && lane == 0;   // (-DVIEKF_STAMPS diagnostic build: who stamps)
+  (void)st0;
+  RES_STAMP(S, st0, 64);
   const double p0rr = uniform_f64(prm.P0_feat[2]);
   // applies the pending fix_depth covariance edits of mailbox `mb` (vi_ekf_helper.cpp:141-151: P(rho,rho) += err^2 / = P0) to the
   // diagonal tiles this wave holds: element a = b = 3 j + 2 of tile (T, T) is feature 5 (T - 1) + j
@@ -114,6 +117,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     });
   };
   __syncthreads();  // B0
+  RES_STAMP(S, st0, 65);
 
   // ---------------- propagate(s)
   const int nkp = MP ? S.kp : 1;
@@ -124,7 +128,9 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     const int r3 = l15 / 3, rm = l15 - 3 * r3;
     for (int kp = 0; kp < nkp; kp++) {
       res_prop_setup<TW>(a, S, tid);   // (B1p, B2p, B2q inside)
+      RES_STAMP(S, st0, 66);
       __syncthreads();  // B3p
+      RES_STAMP(S, st0, 67);
       const double* Z = S.Z;
       const double* phiff = S.phiff;
       auto d_op = [&](auto Tc, int s4) -> double {   // Dblk_T[l15][lg + 4 s4]
@@ -168,6 +174,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
         X[s] = o2;
         group_fence<true>();   // (one tile's operand loads are not hoisted over the previous tile's: they would all be held live)
       });
+      RES_STAMP(S, st0, 68);
       if (MP) res_prop_body<TW>(a, S, tid);   // (single propagate: the service wave does this meanwhile)
       par ^= 1;   // the service wave posted this propagate's fix_depth edits into mailbox par ^ 1
       if (MP && kp + 1 < nkp) {
@@ -194,8 +201,10 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
       for (int e = tid; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
       if (MP && kp + 1 < nkp) apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
     }
+    RES_STAMP(S, st0, 70);
     __syncthreads();  // B4q : the body block copy above is complete
   }
+  RES_STAMP(S, st0, 71);
 
   // ---------------- body tiles: LDS -> registers (they are swept on the matrix cores like every other tile)
   static_for<CNT>([&](auto sc) {
@@ -272,12 +281,14 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     extract(__builtin_amdgcn_readfirstlane(S.mslot[m]), S.Cb);   // first measurement: its columns ARE the current ones (nothing pending)
     if (sq.y >= 0) extract(sq.y, S.Eb + 2 * NQ);     // second one: raw, buffer 1
   }
+  RES_STAMP(S, st0, 72);
   __syncthreads();  // Bp : Pd and the first columns are published
   if (m < S.M && tid < NQ) {   // NaN in the first column pair (the later ones are tested where they are formed)
     const double2 c0 = lds_ld2(S.Cb + 2 * tid);
     if (c0.x != c0.x || c0.y != c0.y) S.sm[44] = 1.0;
   }
   __syncthreads();  // B1 : the service published the first measurement's G and verdict
+  RES_STAMP(S, st0, 73);
   int cnt = 0;
   // mu = 1 - lambda of this lane's row inside a feature tile / the body tile, folded into the operand factors
   const bool partial = prm.use_partial_update != 0;
@@ -302,6 +313,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     double* Cn = S.Cb + ((cnt + 1) & 1) * 2 * NQ;
     if (tid == 0) S.sm[44 + (cnt + 2) % 3] = 0.0;   // (the word of the phase after next: nobody reads or sets it in this phase)
     apply_fixes(par ^ 1, fixpending);
+    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 0);
     if (run) {
       const bool odd = (lg & 1) != 0;
       const double ga = odd ? g01 : g00, gb = odd ? g11 : g01;                  // column k & 1 of G
@@ -320,6 +332,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
         X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X[s], 0, 0, 0);
       });
     }
+    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 1);
     // (2) next measurement's column pair:  C_{m+1}[q] = E[q] - Lambda(q, zeta_c) (C G C^T)[q][zeta_c]
     if (snext >= 0 && tid < NQ) {
       const int q = tid, qs = tile_qrow(snext, 0);
@@ -340,15 +353,19 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
       *reinterpret_cast<double2*>(Cn + 2 * q) = e;
       if (e.x != e.x || e.y != e.y) S.sm[44 + (cnt + 1) % 3] = 1.0;
     }
+    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 2);
     // (3) raw column pair of the measurement after next, from the swept tiles
     if (sq2.y >= 0 && mnext < S.M && !RES_ABLATE(S, 4)) extract(sq2.y, S.Eb + (cnt & 1) * 2 * NQ);
+    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 3);
     par ^= 1;
     cnt++;
     sq = sq2;
     __syncthreads();  // B1 (the only barrier of an update)
+    RES_STAMP(S, st0 && cnt <= 8, 112 + cnt - 1);
     m = mnext;
   }
   apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
+  RES_STAMP(S, st0, 74);
 
   // ---------------- store: the lower triangle, straight from the tiles (lanes along the rows of P) ----------------
   {
@@ -363,6 +380,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
       }
     });
   }
+  RES_STAMP(S, st0, 75);
 }
 
 }  // namespace viekf
