@@ -117,6 +117,12 @@ int viekf_batch_get_params(const viekf_batch *b, viekf_params *out);   /* the pa
  * NULL = HIP's default (null) stream.  A new batch starts on a private non-blocking stream. */
 int viekf_batch_set_stream(viekf_batch *b, void *hip_stream);
 int viekf_batch_sync(viekf_batch *b);
+/* Host-pointer calls normally return when their work is done.  With async_host != 0 the INPUT-ONLY host-pointer calls
+ * (viekf_batch_propagate / _propagate_to, and _update_feat / _step / _step_n when `result` is NULL) copy their arguments into
+ * pinned staging at call time and return as soon as the launch is queued -- the caller's arrays are free to change at once; every
+ * call that hands results back to the host, and viekf_batch_sync, still wait.  The host sequencer (viekf_seq_*) drives its
+ * batch this way: a replay of k propagates is k queued launches, not k round trips. */
+int viekf_batch_set_async(viekf_batch *b, int32_t async_host);
 /* kernel family: 0 = auto, 1 = streaming (P in HBM/L2, any num_features), 2 = resident (P on chip) */
 int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
 /* Kernel selection knobs for tests and experiments (no reference counterpart; the defaults are what a caller gets and nothing
@@ -298,6 +304,12 @@ int viekf_seq_propagate(viekf_seq *s, const double *u /* [batch][6] */, double t
  * result [batch] (may be NULL): viekf_meas_result per filter */
 int viekf_seq_add_measurement(viekf_seq *s, double t, int32_t type, const double *z, int32_t zdim, const double *R,
                               int32_t rdim, int32_t active, const int32_t *id, const double *depth, int32_t *result);
+/* A whole camera frame in one call: the `count` FEAT entries that `count` calls of add_measurement(t, z_k, FEAT, R, active, id_k,
+ * depth_k), k = 0 .. count - 1, would queue (the loops of src/vi_ekf_ros.cpp:288-306 and test/vi_ekf_test.cpp:30-31).
+ * z [batch][count][2]; id [batch][count]; depth [batch][count] or NULL (NaN); R 2x2 column-major; result [batch][count] or NULL.
+ * t_per_filter [batch] (independent clocks only; NULL = the one stamp t) and mask [batch] as in viekf_seq_add_measurement_t. */
+int viekf_seq_add_frame(viekf_seq *s, double t, const double *t_per_filter, int32_t count, const double *z, const double *R,
+                        int32_t active, const int32_t *id, const double *depth, const uint8_t *mask, int32_t *result);
 /* gated_ids [batch][cap] / gated_count [batch] (both may be NULL): global ids of the FEAT measurements gated in this call */
 int viekf_seq_handle_measurements(viekf_seq *s, int32_t *gated_ids, int32_t cap, int32_t *gated_count);
 /* ids [batch][count] global ids to keep (pad with -1); did_reset [batch], edges [batch][17] (may be NULL): keyframe resets

@@ -230,7 +230,7 @@ def test_reference_call_sites_flight_matches_restated_plumbing(tmp_path):
         imu_cb(t, imu, True, k > 10, qa, k % 7 == 3)
         if k % 6 == 2:
             tz = t - 0.0105 if k > 6 else t                  # a delayed frame: rewind + replay
-            ids = ids_all if k < 30 else [0, 2, 5]
+            ids = ids_all if k < 30 else ([0, 2, 5] if k <= 38 else [0, 5])   # (an unknown id would start a new feature)
             frame_cb(tz, ids, [pix[i] + rng.normal(0, 0.5, 2) for i in ids], [3.0 + 0.5 * i + rng.normal(0, 0.05) for i in ids],
                      k % 12 == 8)
         if k % 9 == 4:

@@ -87,6 +87,10 @@ struct viekf_batch {
   int* d_resmap = nullptr;             // fused-step kernel: block ownership map [RB][TW] of the chosen instance (build_resmap)
   int* d_ringslot = nullptr;           // [B] staging of per-filter ring slots (viekf_batch_snapshot_filters / _restore_filters)
   // viekf_batch_set_tuning (tests / experiments; the defaults are what a caller gets)
+  // async host inputs (viekf_batch_set_async): pinned staging ring the arguments are copied into at call time
+  bool async_host = false;
+  char* h_pin = nullptr;
+  size_t pin_bytes = 0, pin_used = 0;
   int tile_inst = -1;          // tile family (P as MFMA accumulator tiles): index into kTileInst, -1 = not used for this batch
   size_t tile_lds = 0;
   int tune_tiles = 1;          // 0: never the tile family
@@ -125,6 +129,23 @@ int stage_begin(viekf_batch* b, size_t need) {
     b->stage_bytes = need;
   }
   b->stage_used = 0;
+  if (b->async_host) {
+    // A pinned RING on the host side (the copies out of it run later, in stream order) and a ring on the device side too: the
+    // previous call's kernel may still be reading its staged arguments, and although the next call's copy is ordered behind it
+    // on the stream, a ring lets the copy engine run ahead.  Both wrap after a stream synchronise.
+    const size_t ring = std::max<size_t>(64 * need, 8u << 20);
+    if (ring > b->pin_bytes) {
+      HIP_TRY(hipStreamSynchronize(b->stream));
+      if (b->h_pin) HIP_TRY(hipHostFree(b->h_pin));
+      b->h_pin = nullptr; b->pin_bytes = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_pin), ring, hipHostMallocDefault));
+      b->pin_bytes = ring; b->pin_used = 0;
+    }
+    if (b->pin_used + need > b->pin_bytes) {   // wrap: everything queued so far has to have left the ring
+      HIP_TRY(hipStreamSynchronize(b->stream));
+      b->pin_used = 0;
+    }
+  }
   return VIEKF_OK;
 }
 
@@ -140,7 +161,15 @@ int in_ptr(viekf_batch* b, const Tp* src, size_t count, viekf_mem where, const T
   if (!src) { *out = nullptr; return VIEKF_OK; }
   if (where == VIEKF_DEVICE) { *out = src; return VIEKF_OK; }
   Tp* d = static_cast<Tp*>(stage_take(b, count * sizeof(Tp)));
-  HIP_TRY(hipMemcpyAsync(d, src, count * sizeof(Tp), hipMemcpyHostToDevice, b->stream));
+  const void* from = src;
+  if (b->async_host) {   // the caller's array may change as soon as the call returns: its bytes go through pinned memory now
+    const size_t bytes = count * sizeof(Tp), off = (b->pin_used + 255) & ~size_t(255);
+    if (off + bytes > b->pin_bytes) return fail(VIEKF_ERR_INVALID, "async staging overflow");   // (stage_begin sized it)
+    std::memcpy(b->h_pin + off, src, bytes);
+    b->pin_used = off + bytes;
+    from = b->h_pin + off;
+  }
+  HIP_TRY(hipMemcpyAsync(d, from, count * sizeof(Tp), hipMemcpyHostToDevice, b->stream));
   *out = d;
   return VIEKF_OK;
 }
@@ -767,6 +796,7 @@ int viekf_batch_destroy(viekf_batch* b) {
   void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_active, b->d_ringslot, b->d_resmap};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  if (b->h_pin) (void)hipHostFree(b->h_pin);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return VIEKF_OK;
@@ -838,6 +868,14 @@ int viekf_batch_sync(viekf_batch* b) {
   if (int rc = check_batch(b)) return rc;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_set_async(viekf_batch* b, int32_t async_host) {
+  if (int rc = check_batch(b)) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->async_host = async_host != 0;
   return VIEKF_OK;
 }
 
@@ -956,7 +994,7 @@ int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, vie
   } else {
     if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
   }
-  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
 
@@ -1030,7 +1068,7 @@ static int update_or_step(viekf_batch* b, const double* u, const double* dt, boo
   }
   if (where == VIEKF_HOST) {
     if (result && M > 0) HIP_TRY(hipMemcpyAsync(result, d_res, sizeof(int32_t) * BM, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (!b->async_host || (result && M > 0)) HIP_TRY(hipStreamSynchronize(b->stream));
   }
   return VIEKF_OK;
 }
@@ -1435,7 +1473,7 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
     if (int rc = viekf_batch_select(b, dst_slot)) return rc;
     if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
   }
-  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
 

@@ -561,12 +561,16 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   s->node.assign((size_t)B * 7, 0.0);                              // Xformd::Identity(), vi_ekf.cpp:38
   for (int b = 0; b < B; b++) s->node[7 * (size_t)b + 3] = 1.0;
   s->node_cov.assign((size_t)B * 36, 0.0);                         // vi_ekf.cpp:39
+  // input-only device steps (propagates, updates whose result codes nobody asked for) are queued, not waited for: a replay of k
+  // propagates is k launches back to back; every call that returns data to the host still synchronises
+  if (int rc = viekf_batch_set_async(core, 1)) { delete s; return rc; }
   *out = s;
   return VIEKF_OK;
 }
 
 int viekf_seq_destroy(viekf_seq* s) {
   if (s && s->core) {   // hand the live state back to the batch's own buffers
+    (void)viekf_batch_set_async(s->core, 0);
     (void)viekf_batch_history_resize(s->core, 0);
   }
   delete s;
@@ -593,6 +597,7 @@ int viekf_seq_create_independent(viekf_batch* core, int32_t state_hist, int32_t 
   s->node.assign((size_t)B * 7, 0.0);
   for (int b = 0; b < B; b++) s->node[7 * (size_t)b + 3] = 1.0;
   s->node_cov.assign((size_t)B * 36, 0.0);
+  if (int rc = viekf_batch_set_async(core, 1)) { delete s; return rc; }
   *out = s;
   return VIEKF_OK;
 }
@@ -712,6 +717,34 @@ int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double
     s->zbuf.insert(s->zbuf.begin() + (long)k, std::move(m));                           // :169-175
   }
   if (result) std::memcpy(result, res.data(), sizeof(int32_t) * B);
+  return VIEKF_OK;
+}
+
+// A camera frame in ONE call: the `count` FEAT entries of a frame, exactly what `count` calls of add_measurement(t, z_k, FEAT, R,
+// active, id_k, depth_k) in the order k = 0 .. count - 1 do (the loop of src/vi_ekf_ros.cpp:288-306 / test/vi_ekf_test.cpp:30-31) --
+// without the per-call crossing of the language boundary.  z [B][count][2], id [B][count], depth [B][count] or NULL (NaN),
+// t: one stamp, or with t_per_filter [B] (independent clocks) and an optional mask [B]; result [B][count] or NULL.
+int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int32_t count, const double* z, const double* R,
+                        int32_t active, const int32_t* id, const double* depth, const uint8_t* mask, int32_t* result) {
+  if (!s || !z || !R || !id || count < 0) return VIEKF_ERR_INVALID;
+  if (t_per_filter && !s->indep) return VIEKF_ERR_INVALID;
+  const int B = s->B;
+  std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
+  std::vector<int32_t> ik(B), rk(B);
+  for (int k = 0; k < count; k++) {
+    for (int b = 0; b < B; b++) {
+      const size_t e = (size_t)b * count + k;
+      zk[2 * (size_t)b] = z[2 * e]; zk[2 * (size_t)b + 1] = z[2 * e + 1];
+      ik[b] = id[e];
+      if (depth) dk[b] = depth[e];
+    }
+    int rc;
+    if (t_per_filter) rc = viekf_seq_add_measurement_t(s, t_per_filter, VIEKF_FEAT, zk.data(), 2, R, 2, active, ik.data(), dk.data(), mask, rk.data());
+    else rc = viekf_seq_add_measurement(s, t, VIEKF_FEAT, zk.data(), 2, R, 2, active, ik.data(), dk.data(), rk.data());
+    if (rc) return rc;
+    if (result)
+      for (int b = 0; b < B; b++) result[(size_t)b * count + k] = rk[b];
+  }
   return VIEKF_OK;
 }
 

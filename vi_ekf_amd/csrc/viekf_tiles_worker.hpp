@@ -67,19 +67,51 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   (void)TPW;
 
   // ---------------- load: feature/feature tiles from the lower triangle of P (a diagonal tile mirrors it), body columns -> LDS
+  // Addressing: element (a = lg + 4 r, b = l15) of tile (TI, TJ) is P[rowbase(TI) + b + (rowbase(TJ) + a) ld]: the lane's part
+  // l15 + lg ld is ONE 32-bit register for every load and store of the kernel, the tile's part and 4 r ld go into the scalar base
+  // (four 64-bit scalar adds per tile instead of a 64-bit vector address per element: the first version of this file spent 76 k
+  // clocks in its load phase and 62 k in its store, most of it address arithmetic and its spills).
+  auto rowbase = [](int Tt) { return Tt == 0 ? 0 : 16 + 15 * (Tt - 1); };
+  // (the lane parts are re-derived where they are used -- load and store, the two ends of the kernel -- from a laundered lane
+  //  index: held live across the update loop they were spilled and re-loaded in every phase)
+  struct LaneOff { unsigned vo, vom[4]; bool low[4]; };
+  auto lane_off = [&]() {
+    LaneOff o;
+    const int ln = opaque(lane), b15 = ln & 15, g4 = ln >> 4;
+    o.vo = (unsigned)b15 + (unsigned)g4 * (unsigned)ld;
+    // a diagonal tile reads (and a store writes) only P's lower triangle: b >= a; the upper half comes from the mirrored element
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      o.low[r] = b15 >= g4 + 4 * r;
+      o.vom[r] = o.low[r] ? (unsigned)b15 + (unsigned)(g4 + 4 * r) * (unsigned)ld : (unsigned)(g4 + 4 * r) + (unsigned)b15 * (unsigned)ld;
+    }
+    return o;
+  };
+  // validity of this lane's row b = l15 / column a = lg + 4 r inside a FULL feature tile (index 15 is the pad) and inside the LAST
+  // one (NT - 1: features past N do not exist); body tile: everything valid
+  auto row_ok = [&](int Tt) { return Tt == 0 ? true : (Tt == NT - 1 ? (l15 < 15 && 15 * (NT - 2) + l15 < nf) : l15 < 15); };
+  auto col_ok = [&](int Tt, int r) {
+    const int aa = lg + 4 * r;
+    return Tt == 0 ? true : (Tt == NT - 1 ? (aa < 15 && 15 * (NT - 2) + aa < nf) : aa < 15);
+  };
   v4f64 X[CNT];
+  const LaneOff lo_ = lane_off();
   static_for<CNT>([&](auto sc) {
     constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
     v4f64 x = {0.0, 0.0, 0.0, 0.0};
     if (TJ >= 1) {
-      const int rb = tile_prow(TI, l15, nf);
+      const double* base = P + rowbase(TI) + (long)rowbase(TJ) * ld;   // (wave-uniform: scalar registers)
+      if (row_ok(TI)) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ca = tile_prow(TJ, lg + 4 * r, nf);
-        if (rb >= 0 && ca >= 0) x[r] = (TI == TJ) ? P[max(rb, ca) + (long)min(rb, ca) * ld] : P[rb + (long)ca * ld];
+        for (int r = 0; r < 4; r++) {
+          if (TI == TJ) { if (col_ok(TJ, r)) x[r] = base[lo_.vom[r]]; }
+          else if (r < 3 && TJ != NT - 1) x[r] = (base + 4L * r * ld)[lo_.vo];   // (a < 15 for r < 3: no test)
+          else if (col_ok(TJ, r)) x[r] = (base + 4L * r * ld)[lo_.vo];
+        }
       }
     }
     X[s] = x;
+    if ((s & 3) == 3) group_fence<true>();   // (four tiles' loads in flight; all 88 at once would hold 88 addresses live)
   });
   for (int e = tid; e < nf * 16; e += TW) {   // body columns -> LDS (coalesced along rows)
     const int k = e / nf, row = e - k * nf;
@@ -230,6 +262,9 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   // reaches the code of exactly this wave's tiles of that cross.
   auto extract = [&](int g, double* dst) {
     const int Ts = 1 + g / 5, w0 = 3 * (g % 5);   // (wave-uniform)
+    // (lane parts re-derived from a laundered lane index: everything computed from them here is otherwise hoisted out of the
+    //  update loop, held across it -- and spilled)
+    const int ln_ = opaque(lane), l15 = ln_ & 15, lg = ln_ >> 4;
     static_for<NT - 1>([&](auto tc) {
       constexpr int TS = decltype(tc)::value + 1;
       if (Ts != TS) return;
@@ -294,9 +329,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   const bool partial = prm.use_partial_update != 0;
   const double muF = tile_mu(S.lam, 16 + l15, nf, partial), muB = tile_mu(S.lam, l15, nf, partial);
   const double mq_own = tile_mu(S.lam, min(tid, NQ - 1), nf, partial);                         // of the row this thread brings up to date
-  const double mz0 = tile_mu(S.lam, 16, nf, partial), mz1 = tile_mu(S.lam, 17, nf, partial);   // lambda_feat is the same for every slot
-  const double fAF = (lg < 2) ? 1.0 : muF, fAB = (lg < 2) ? 1.0 : muB;        // TJ side:  C[k & 1] x {1, 1, mu, mu}
-  const double fBF = (lg < 2) ? -1.0 : muF, fBB = (lg < 2) ? -1.0 : muB;      // TI side: Kg[k & 1] x {-1, -1, mu, mu}
+  const double mz0 = uniform_f64(tile_mu(S.lam, 16, nf, partial)), mz1 = uniform_f64(tile_mu(S.lam, 17, nf, partial));   // lambda_feat is the same for every slot
   // ONE barrier per update.  Inside a phase the worker waves (1) form their operands from the current column pair C_m and the
   // 2x2 G_m = Hb^T S^-1 Hb of the service wave and issue one MFMA per tile:  P -= Lambda o (C G C^T)  (= the reference's
   // (I-KH)P(I-KH)^T + KRK^T - P restricted by Lambda, vi_ekf_meas.cpp:254-257, for K = C Hb^T S^-1), (2) bring the NEXT
@@ -314,45 +347,62 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     if (tid == 0) S.sm[44 + (cnt + 2) % 3] = 0.0;   // (the word of the phase after next: nobody reads or sets it in this phase)
     apply_fixes(par ^ 1, fixpending);
     RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 0);
+    // (2) is spread over the MFMA sequence of (1): a wave issues in order, and a matrix instruction holds the next one back for
+    // its 64 cycles -- whatever sits between two of them in program order is free.  Rows of tiles in turn (a wave's slots are
+    // ordered by TI): the column pair's rows of tile row TR are read two rows ahead, the A-side operand of every tile index is
+    // kept (a later row needs all TJ <= TI), the B-side one lives for its row only.
+    const bool fix = snext >= 0 && tid < NQ;
+    const int fq = min(tid, NQ - 1), qs = tile_qrow(max(snext, 0), 0);
+    const double* En = S.Eb + ((cnt + 1) & 1) * 2 * NQ;
     if (run) {
       const bool odd = (lg & 1) != 0;
+      const double fAF = (lg < 2) ? 1.0 : muF, fAB = (lg < 2) ? 1.0 : muB;        // TJ side:  C[k & 1] x {1, 1, mu, mu}
+      const double fBF = (lg < 2) ? -1.0 : muF, fBB = (lg < 2) ? -1.0 : muB;      // TI side: Kg[k & 1] x {-1, -1, mu, mu}
       const double ga = odd ? g01 : g00, gb = odd ? g11 : g01;                  // column k & 1 of G
       const double gaF = ga * fBF, gbF = gb * fBF, gaB = ga * fBB, gbB = gb * fBB;
       const double* Cl = Cc + 2 * l15;
-      const double* Ck = Cl + (lg & 1);
-      double bop = 0.0;
-      static_for<CNT>([&](auto sc) {
-        constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
-        constexpr int prevTI = (s == 0) ? -1 : Map::ti(W, s == 0 ? 0 : s - 1);
-        if (TI != prevTI) {   // (a wave's slots are ordered by TI: the TI-side operand serves the whole tile row)
-          const double2 cI = lds_ld2(Cl + 32 * TI);
-          bop = (TI == 0) ? fma(cI.y, gbB, cI.x * gaB) : fma(cI.y, gbF, cI.x * gaF);
+      double aop[NT];
+      double2 craw[NT];
+      double2 fe = {0.0, 0.0}, fc = fe;
+      craw[0] = lds_ld2(Cl);
+      if (NT > 1) craw[1] = lds_ld2(Cl + 32);
+      constexpr int FL = NT > 6 ? 3 : 0, FC = NT > 6 ? 6 : NT - 1;   // rows after which the next pair's inputs are read / it is formed
+      static_for<NT>([&](auto tc) {
+        constexpr int TR = decltype(tc)::value;
+        if (TR + 2 < NT) craw[TR + 2 < NT ? TR + 2 : 0] = lds_ld2(Cl + 32 * (TR + 2));
+        const double2 c = craw[TR];
+        aop[TR] = (odd ? c.y : c.x) * ((TR == 0) ? fAB : fAF);
+        const double bop = (TR == 0) ? fma(c.y, gbB, c.x * gaB) : fma(c.y, gbF, c.x * gaF);
+        static_for<CNT>([&](auto sc) {
+          constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+          if (TI == TR) X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[TJ], bop, X[s], 0, 0, 0);
+        });
+        // next measurement's column pair:  C_{m+1}[q] = E[q] - Lambda(q, zeta_c) (C G C^T)[q][zeta_c], one row per thread
+        if (TR == FL && snext >= 0) { fe = lds_ld2(En + 2 * fq); fc = lds_ld2(Cc + 2 * fq); }
+        if (TR == FC && snext >= 0) {
+          const double2 fcs0 = lds_ld2(Cc + 2 * qs), fcs1 = lds_ld2(Cc + 2 * qs + 2), fes = lds_ld2(En + 2 * qs);
+          const double kg0 = fma(fc.y, g01, fc.x * g00), kg1 = fma(fc.y, g11, fc.x * g01);
+          double mq = mq_own;
+          asm volatile("" : "+v"(mq));   // (Lambda's factors are formed here, not hoisted and held across the loop)
+          fe.x = fma(-fma(-mq, mz0, 1.0), fma(kg1, fcs0.y, kg0 * fcs0.x), fe.x);
+          fe.y = fma(-fma(-mq, mz1, 1.0), fma(kg1, fcs1.y, kg0 * fcs1.x), fe.y);
+          // the feature's own 2x2 stays exactly symmetric: element (zeta1, zeta0) takes the value row zeta0 forms for (zeta0, zeta1)
+          const double ks0 = fma(fcs0.y, g01, fcs0.x * g00), ks1 = fma(fcs0.y, g11, fcs0.x * g01);
+          const double alt = fma(-fma(-mz0, mz1, 1.0), fma(ks1, fcs1.y, ks0 * fcs1.x), fes.y);
+          if (fq == qs + 1) fe.x = alt;
+          if (fix) {
+            *reinterpret_cast<double2*>(Cn + 2 * fq) = fe;
+            if (fe.x != fe.x || fe.y != fe.y) S.sm[44 + (cnt + 1) % 3] = 1.0;
+          }
         }
-        const double aop = Ck[32 * TJ] * ((TJ == 0) ? fAB : fAF);
-        X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X[s], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps this placement: the scheduler would otherwise cluster loads and arithmetic)
       });
-    }
-    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 1);
-    // (2) next measurement's column pair:  C_{m+1}[q] = E[q] - Lambda(q, zeta_c) (C G C^T)[q][zeta_c]
-    if (snext >= 0 && tid < NQ) {
-      const int q = tid, qs = tile_qrow(snext, 0);
-      const double* En = S.Eb + ((cnt + 1) & 1) * 2 * NQ;
-      double2 e = lds_ld2(En + 2 * q);
-      if (run) {
-        const double2 c = lds_ld2(Cc + 2 * q), cs0 = lds_ld2(Cc + 2 * qs), cs1 = lds_ld2(Cc + 2 * qs + 2);
-        const double2 es = lds_ld2(En + 2 * qs);
-        const double mq = mq_own;
-        const double kg0 = fma(c.y, g01, c.x * g00), kg1 = fma(c.y, g11, c.x * g01);
-        e.x = fma(-fma(-mq, mz0, 1.0), fma(kg1, cs0.y, kg0 * cs0.x), e.x);
-        e.y = fma(-fma(-mq, mz1, 1.0), fma(kg1, cs1.y, kg0 * cs1.x), e.y);
-        // the feature's own 2x2 stays exactly symmetric: element (zeta1, zeta0) takes the value row zeta0 forms for (zeta0, zeta1)
-        const double ks0 = fma(cs0.y, g01, cs0.x * g00), ks1 = fma(cs0.y, g11, cs0.x * g01);
-        const double alt = fma(-fma(-mz0, mz1, 1.0), fma(ks1, cs1.y, ks0 * cs1.x), es.y);
-        if (q == qs + 1) e.x = alt;
-      }
-      *reinterpret_cast<double2*>(Cn + 2 * q) = e;
+    } else if (fix) {   // gated / NaN-guarded: nothing to apply, the raw pair is the current one
+      const double2 e = lds_ld2(En + 2 * fq);
+      *reinterpret_cast<double2*>(Cn + 2 * fq) = e;
       if (e.x != e.x || e.y != e.y) S.sm[44 + (cnt + 1) % 3] = 1.0;
     }
+    RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 1);
     RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 2);
     // (3) raw column pair of the measurement after next, from the swept tiles
     if (sq2.y >= 0 && mnext < S.M && !RES_ABLATE(S, 4)) extract(sq2.y, S.Eb + (cnt & 1) * 2 * NQ);
@@ -370,14 +420,19 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   // ---------------- store: the lower triangle, straight from the tiles (lanes along the rows of P) ----------------
   {
     double* Po = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
+    const LaneOff so_ = lane_off();
     static_for<CNT>([&](auto sc) {
       constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
-      const int rb = tile_prow(TI, l15, nf);
+      double* base = Po + rowbase(TI) + (long)rowbase(TJ) * ld;
+      if (row_ok(TI)) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ca = tile_prow(TJ, lg + 4 * r, nf);
-        if (rb >= 0 && ca >= 0 && (TI != TJ || rb >= ca)) Po[rb + (long)ca * ld] = X[s][r];
+        for (int r = 0; r < 4; r++) {
+          if (TI == TJ) { if (so_.low[r] && col_ok(TJ, r)) (base + 4L * r * ld)[so_.vo] = X[s][r]; }
+          else if ((r < 3 && TJ != NT - 1) || TJ == 0) (base + 4L * r * ld)[so_.vo] = X[s][r];
+          else if (col_ok(TJ, r)) (base + 4L * r * ld)[so_.vo] = X[s][r];
+        }
       }
+      if ((s & 3) == 3) group_fence<true>();
     });
   }
   RES_STAMP(S, st0, 75);

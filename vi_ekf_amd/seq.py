@@ -28,6 +28,14 @@ def _bind():
     L.viekf_seq_add_measurement_t.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     L.viekf_seq_get_global_pose.argtypes = [vp, vp, vp]
     L.viekf_seq_get_global_cov.argtypes = [vp, vp]
+    L.viekf_seq_add_frame.argtypes = [vp, C.c_double, vp, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
+    L.viekf_seq_propagate_state.argtypes = [vp, vp, C.c_double, C.c_int32]
+    L.viekf_seq_set_x0.argtypes = [vp, vp]
+    L.viekf_seq_set_imu_bias.argtypes = [vp, vp, vp]
+    L.viekf_seq_keyframe_reset.argtypes = [vp, vp, vp]
+    L.viekf_seq_get_features.argtypes = [vp, vp, vp, vp]
+    L.viekf_seq_get_feat.argtypes = [vp, vp, vp, vp]
+    L.viekf_seq_drop_features.argtypes = [vp, vp, C.c_int32]
     L._seq_bound = True
     return L
 
@@ -88,6 +96,26 @@ class SeqVIEKF:
         mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         capi.check(self._L.viekf_seq_add_measurement_t(self._h, _p(tt), int(mtype), _p(z), z.shape[1], _p(Rf), R.shape[0],
                                                        int(bool(active)), idp, dp, None if mk is None else _p(mk), _p(res)))
+        return res
+
+    def add_frame(self, t, z, R, ids, active=True, depth=None, mask=None):
+        """a whole camera frame in one call (viekf_seq_add_frame): z [B][count][2], ids [B][count] (or [count]: the same for every
+        filter), depth [B][count] or None -> results [B][count]; what count add_measurement(FEAT) calls in order do"""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        count = z.shape[1]
+        assert z.shape == (self.B, count, 2)
+        ida = np.ascontiguousarray(np.broadcast_to(np.asarray(ids, dtype=np.int32), (self.B, count)))
+        R = np.asfortranarray(np.atleast_2d(np.asarray(R, dtype=np.float64)))
+        Rf = np.ascontiguousarray(R.ravel(order="F"))
+        da = None if depth is None else np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float64), (self.B, count)))
+        res = np.zeros((self.B, count), dtype=np.int32)
+        tt = None
+        t0 = float(t) if np.ndim(t) == 0 else 0.0
+        if np.ndim(t) != 0:
+            tt = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.B,)))
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        capi.check(self._L.viekf_seq_add_frame(self._h, t0, None if tt is None else _p(tt), count, _p(z), _p(Rf), int(bool(active)), _p(ida),
+                                               None if da is None else _p(da), None if mk is None else _p(mk), _p(res)))
         return res
 
     def handle_measurements(self, cap=64):
