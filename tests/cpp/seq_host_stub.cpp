@@ -1,0 +1,181 @@
+// seq_host_stub.cpp -- TEST ONLY (never shipped, never linked into libviekf_hip.so): a host stand-in for the viekf_batch_* entry
+// points that viekf_seq.cpp calls, so that the sequencer's queue / ring / rewind code (977 lines of deque and index arithmetic
+// that otherwise only ever run against the GPU library) can be built with -fsanitize=address,undefined and driven on the CPU
+// (tests/test_seq_sanitized.py).  It is NOT a filter: a propagate adds dt to a per-filter counter in x[0] and counts in x[1], an
+// update counts in x[2], the ring copies whole states -- enough for the driver to check that every filter ends where its own
+// time line says it should, and for the sanitizers to see every index the sequencer forms.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/viekf.h"
+
+struct viekf_batch {
+  int B, N, nx, n;
+  viekf_params p;
+  std::vector<double> x, P;            // live [B][nx], [B][n*n]
+  std::vector<int32_t> len;
+  std::vector<std::vector<double>> rx, rP;   // ring slots
+  int live = -1;
+  std::vector<uint8_t> active;
+  bool active_on = false;
+  long calls = 0;
+  double* xs(int slot) { return slot < 0 ? x.data() : rx[(size_t)slot].data(); }
+  double* Ps(int slot) { return slot < 0 ? P.data() : rP[(size_t)slot].data(); }
+  bool on(int b) const { return !active_on || active[(size_t)b]; }
+};
+
+extern "C" {
+const char* viekf_last_error(void) { return "stub"; }
+int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* p, int32_t, viekf_batch** out) {
+  viekf_batch* b = new viekf_batch;
+  b->B = batch; b->N = num_features; b->nx = 17 + 5 * num_features; b->n = 16 + 3 * num_features; b->p = *p;
+  b->x.assign((size_t)batch * b->nx, 0.0); b->P.assign((size_t)batch * b->n * b->n, 0.0); b->len.assign(batch, 0);
+  for (int i = 0; i < batch; i++) b->x[(size_t)i * b->nx + 6] = 1.0;
+  *out = b;
+  return VIEKF_OK;
+}
+int viekf_batch_destroy(viekf_batch* b) { delete b; return VIEKF_OK; }
+int viekf_batch_dims(const viekf_batch* b, int32_t* batch, int32_t* nf, int32_t* nx, int32_t* n) {
+  if (batch) *batch = b->B; if (nf) *nf = b->N; if (nx) *nx = b->nx; if (n) *n = b->n;
+  return VIEKF_OK;
+}
+int viekf_batch_get_params(const viekf_batch* b, viekf_params* out) { *out = b->p; return VIEKF_OK; }
+int viekf_batch_set_async(viekf_batch*, int32_t) { return VIEKF_OK; }
+int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
+  if (b->live >= 0) { b->x = b->rx[(size_t)b->live]; b->P = b->rP[(size_t)b->live]; b->live = -1; }
+  b->rx.assign((size_t)depth, std::vector<double>(b->x.size(), NAN));
+  b->rP.assign((size_t)depth, std::vector<double>(b->P.size(), NAN));
+  return VIEKF_OK;
+}
+int viekf_batch_snapshot(viekf_batch* b, int32_t slot) {
+  if (slot < 0 || slot >= (int)b->rx.size()) return VIEKF_ERR_INVALID;
+  if (slot != b->live) { b->rx[(size_t)slot].assign(b->xs(b->live), b->xs(b->live) + b->x.size()); b->rP[(size_t)slot].assign(b->Ps(b->live), b->Ps(b->live) + b->P.size()); }
+  return VIEKF_OK;
+}
+int viekf_batch_select(viekf_batch* b, int32_t slot) {
+  if (slot < -1 || slot >= (int)b->rx.size()) return VIEKF_ERR_INVALID;
+  b->live = slot;
+  return VIEKF_OK;
+}
+static void prop(viekf_batch* b, int src, int dst, const double* u, const double* dt) {
+  for (int i = 0; i < b->B; i++) {
+    double* xo = b->xs(dst) + (size_t)i * b->nx;
+    const double* xi = b->xs(src) + (size_t)i * b->nx;
+    if (xo != xi) std::memcpy(xo, xi, sizeof(double) * b->nx);
+    if (!b->on(i)) continue;
+    xo[0] += dt[i]; xo[1] += 1.0; xo[3] += u[6 * (size_t)i];
+  }
+  if (src != dst) std::memcpy(b->Ps(dst), b->Ps(src), sizeof(double) * b->P.size());
+}
+int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, viekf_mem) { b->calls++; prop(b, b->live, b->live, u, dt); return VIEKF_OK; }
+int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, int32_t dst, viekf_mem) {
+  if (dst < 0 || dst >= (int)b->rx.size() || b->active_on) return VIEKF_ERR_INVALID;
+  b->calls++;
+  prop(b, b->live, dst, u, dt);
+  b->live = dst;
+  return VIEKF_OK;
+}
+int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot, int32_t M, const double* R, int32_t, int32_t* result, viekf_mem) {
+  b->calls++;
+  for (int i = 0; i < b->B; i++)
+    for (int m = 0; m < M; m++) {
+      const int sl = slot[(size_t)i * M + m];
+      int code = 0;
+      if (sl < 0) code = -1;
+      else if (sl >= b->len[(size_t)i]) code = 3;
+      else if (std::isnan(z[((size_t)i * M + m) * 2])) code = 2;
+      else if (b->on(i)) b->xs(b->live)[(size_t)i * b->nx + 2] += 1.0;
+      if (result) result[(size_t)i * M + m] = b->on(i) ? code : -1;
+    }
+  (void)R;
+  return VIEKF_OK;
+}
+int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zdim, const double*, int32_t, int32_t, const int32_t* slot,
+                       const uint8_t* active, int32_t* result, viekf_mem) {
+  b->calls++;
+  for (int i = 0; i < b->B; i++) {
+    int code = 0;
+    if (active && active[i] == 2) code = -1;
+    else if (slot && (type == 5 || type == 6 || type == 8 || type == 9) && (slot[i] < 0 || slot[i] >= b->len[(size_t)i])) code = slot[i] < 0 ? -1 : 3;
+    else if (std::isnan(z[(size_t)i * zdim])) code = 2;
+    else b->xs(b->live)[(size_t)i * b->nx + 4] += 1.0;
+    if (result) result[i] = code;
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_init_feature(viekf_batch* b, const double* pix, const double*, const uint8_t* mask, int32_t* ok, viekf_mem) {
+  for (int i = 0; i < b->B; i++) {
+    int took = 0;
+    if ((!mask || mask[i]) && b->len[(size_t)i] < b->N) {
+      b->xs(b->live)[(size_t)i * b->nx + 17 + 5 * b->len[(size_t)i]] = pix[2 * (size_t)i];
+      b->len[(size_t)i]++;
+      took = 1;
+    }
+    if (ok) ok[i] = took;
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem) {
+  for (int i = 0; i < b->B; i++) {
+    int k = 0;
+    double* x = b->xs(b->live) + (size_t)i * b->nx;
+    for (int f = 0; f < b->len[(size_t)i]; f++)
+      if (keep[(size_t)i * b->N + f]) { std::memmove(x + 17 + 5 * k, x + 17 + 5 * f, sizeof(double) * 5); k++; }
+    for (int f = k; f < b->N; f++) std::memset(x + 17 + 5 * f, 0, sizeof(double) * 5);
+    b->len[(size_t)i] = k;
+    if (new_len) new_len[i] = k;
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge, viekf_mem) {
+  for (int i = 0; i < b->B; i++) {
+    if (mask && !mask[i]) continue;
+    double* x = b->xs(b->live) + (size_t)i * b->nx;
+    if (edge) { double* e = edge + 17 * (size_t)i; std::memset(e, 0, sizeof(double) * 17); e[0] = x[0]; e[3] = 1.0; }
+    x[5] += 1.0;
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_get_state(viekf_batch* b, double* x, double* P, int32_t* len, viekf_mem) {
+  if (x) std::memcpy(x, b->xs(b->live), sizeof(double) * b->x.size());
+  if (P) std::memcpy(P, b->Ps(b->live), sizeof(double) * b->P.size());
+  if (len) std::memcpy(len, b->len.data(), sizeof(int32_t) * b->B);
+  return VIEKF_OK;
+}
+int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, const int32_t* len, viekf_mem) {
+  if (x) std::memcpy(b->xs(b->live), x, sizeof(double) * b->x.size());
+  if (P) std::memcpy(b->Ps(b->live), P, sizeof(double) * b->P.size());
+  if (len) std::memcpy(b->len.data(), len, sizeof(int32_t) * b->B);
+  return VIEKF_OK;
+}
+int viekf_batch_get_cov_diag(viekf_batch* b, double* d, viekf_mem) { std::memset(d, 0, sizeof(double) * (size_t)b->B * b->n); return VIEKF_OK; }
+int viekf_batch_get_cov_block(viekf_batch* b, int32_t, int32_t, int32_t nr, int32_t nc, double* out, viekf_mem) {
+  std::memset(out, 0, sizeof(double) * (size_t)b->B * nr * nc);
+  return VIEKF_OK;
+}
+int viekf_batch_eval_xdot(viekf_batch* b, const double*, double* xdot, viekf_mem) { std::memset(xdot, 0, sizeof(double) * (size_t)b->B * b->n); return VIEKF_OK; }
+int viekf_batch_eval_h(viekf_batch* b, int32_t, const int32_t*, double* zhat, viekf_mem) { std::memset(zhat, 0, sizeof(double) * 4 * (size_t)b->B); return VIEKF_OK; }
+int viekf_batch_set_active(viekf_batch* b, const uint8_t* mask, viekf_mem) {
+  b->active_on = mask != nullptr;
+  if (mask) b->active.assign(mask, mask + b->B);
+  return VIEKF_OK;
+}
+static int ring_filters(viekf_batch* b, const int32_t* slot, int to_ring) {
+  if (b->live >= 0) return VIEKF_ERR_INVALID;
+  for (int i = 0; i < b->B; i++) {
+    const int sl = slot[i];
+    if (sl < 0) continue;
+    if (sl >= (int)b->rx.size()) return VIEKF_ERR_INVALID;
+    double* rx = b->rx[(size_t)sl].data() + (size_t)i * b->nx;
+    double* lx = b->x.data() + (size_t)i * b->nx;
+    double* rP = b->rP[(size_t)sl].data() + (size_t)i * b->n * b->n;
+    double* lP = b->P.data() + (size_t)i * b->n * b->n;
+    if (to_ring) { std::memcpy(rx, lx, sizeof(double) * b->nx); std::memcpy(rP, lP, sizeof(double) * b->n * b->n); }
+    else { std::memcpy(lx, rx, sizeof(double) * b->nx); std::memcpy(lP, rP, sizeof(double) * b->n * b->n); }
+  }
+  return VIEKF_OK;
+}
+int viekf_batch_snapshot_filters(viekf_batch* b, const int32_t* slot, viekf_mem) { return ring_filters(b, slot, 1); }
+int viekf_batch_restore_filters(viekf_batch* b, const int32_t* slot, viekf_mem) { return ring_filters(b, slot, 0); }
+}  // extern "C"

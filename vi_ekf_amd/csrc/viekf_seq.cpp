@@ -126,6 +126,8 @@ struct viekf_seq {
   std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [B][6]), newest first
   std::deque<SeqMeas> zbuf;                                        // newest first
   std::vector<std::vector<int32_t>> ids;                           // current_feature_ids_ per filter
+  std::vector<std::vector<int32_t>> slot_of;                       // per filter: global id -> local slot (-1: not tracked); the ids
+                                                                   // are the filter's own counter (vi_ekf_feat.cpp:29-30): dense
   std::vector<int32_t> next_id;                                    // next_feature_id_ per filter
   std::vector<std::vector<int32_t>> kf_feats;                      // keyframe_features_ per filter
   std::vector<double> node;                                        // current_node_global_pose_ per filter: {t(3), q(4)}
@@ -138,10 +140,28 @@ struct viekf_seq {
 
 namespace {
 
-int local_id(const viekf_seq* s, int b, int gid) {                 // vi_ekf_helper.cpp:114-125
+// vi_ekf_helper.cpp:114-125 (a linear std::find there; a frame of 50 features on 1024 filters asks 100,000 times per frame: table)
+int local_id(const viekf_seq* s, int b, int gid) {
+  const auto& m = s->slot_of[b];
+  return (gid >= 0 && gid < (int)m.size()) ? m[(size_t)gid] : -1;
+}
+void rebuild_slots(viekf_seq* s, int b) {
+  auto& m = s->slot_of[b];
+  std::fill(m.begin(), m.end(), -1);
   const auto& v = s->ids[b];
-  auto it = std::find(v.begin(), v.end(), gid);
-  return it == v.end() ? -1 : (int)(it - v.begin());
+  for (size_t l = 0; l < v.size(); l++) {
+    if (v[l] < 0) continue;
+    if ((size_t)v[l] >= m.size()) m.resize((size_t)v[l] + 1, -1);
+    m[(size_t)v[l]] = (int32_t)l;
+  }
+}
+void push_feature(viekf_seq* s, int b) {                           // vi_ekf_feat.cpp:29-30: the filter numbers features itself
+  const int32_t gid = s->next_id[b];
+  s->ids[b].push_back(gid);
+  s->next_id[b] += 1;
+  auto& m = s->slot_of[b];
+  if ((size_t)gid >= m.size()) m.resize((size_t)gid + 1, -1);
+  m[(size_t)gid] = (int32_t)s->ids[b].size() - 1;
 }
 
 // ---- log writer (src/vi_ekf/vi_ekf_log.cpp) ------------------------------------------------------------------------------
@@ -556,6 +576,7 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
   s->t.assign(state_hist, NAN);                                    // vi_ekf.cpp:22-27
   s->ids.assign(B, {});
+  s->slot_of.assign(B, {});
   s->next_id.assign(B, 0);
   s->kf_feats.assign(B, {});
   s->node.assign((size_t)B * 7, 0.0);                              // Xformd::Identity(), vi_ekf.cpp:38
@@ -592,6 +613,7 @@ int viekf_seq_create_independent(viekf_batch* core, int32_t state_hist, int32_t 
   std::vector<int32_t> zero(B, 0);
   if (int rc = viekf_batch_snapshot_filters(core, zero.data(), VIEKF_HOST)) { delete s; return rc; }   // x_[0], P_[0]
   s->ids.assign(B, {});
+  s->slot_of.assign(B, {});
   s->next_id.assign(B, 0);
   s->kf_feats.assign(B, {});
   s->node.assign((size_t)B * 7, 0.0);
@@ -659,7 +681,7 @@ int viekf_seq_add_measurement_t(viekf_seq* s, const double* t, int32_t type, con
     std::vector<int32_t> ok(B, 0);
     if (int rc = viekf_batch_init_feature(s->core, z, dep.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
     for (int b = 0; b < B; b++)
-      if (newf[b] && ok[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+      if (newf[b] && ok[b]) push_feature(s, b);
     if (int rc = refresh_slots(s, newf)) return rc;
   }
   if (result) std::memcpy(result, res.data(), sizeof(int32_t) * B);
@@ -709,7 +731,7 @@ int viekf_seq_add_measurement(viekf_seq* s, double t, int32_t type, const double
     std::vector<int32_t> ok(B, 0);
     if (int rc = viekf_batch_init_feature(s->core, z, dep.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
     for (int b = 0; b < B; b++)
-      if (newf[b] && ok[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+      if (newf[b] && ok[b]) push_feature(s, b);
     }
   if (any_present) {
     size_t k = 0;                                                                      // :150-156
@@ -762,7 +784,7 @@ int viekf_seq_init_feature(viekf_seq* s, const double* pix, const double* depth,
   std::vector<int32_t> okv(B, 0);
   if (int rc = viekf_batch_init_feature(s->core, pix, dep.data(), m.data(), okv.data(), VIEKF_HOST)) return rc;
   for (int b = 0; b < B; b++)
-    if (m[b] && okv[b]) { s->ids[b].push_back(s->next_id[b]); s->next_id[b] += 1; }
+    if (m[b] && okv[b]) push_feature(s, b);
   if (s->indep)
     if (int rc = refresh_slots(s, m)) return rc;
   if (ok) std::memcpy(ok, okv.data(), sizeof(int32_t) * B);
@@ -888,6 +910,7 @@ static int keep_features_impl(viekf_seq* s, const int32_t* ids, int32_t count, b
       }
     }
     s->ids[b] = kept;
+    rebuild_slots(s, b);
     if (use_kf && !s->kf_feats[b].empty() &&
         (double)overlap / (double)s->kf_feats[b].size() < s->prm.keyframe_overlap_threshold) {   // :119-130
       reset[b] = 1;
