@@ -110,7 +110,7 @@ def test_keyframe_reset_matches_oracle(N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0), (50, 3)])
+@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0), (50, 3), (50, 5)])
 def test_propagate_to_ring_slot_equals_in_place(N, kernel):
     """zero-copy history: propagate_to writes the next ring slot and selects it; the old slot keeps the old state"""
     import ctypes as C
@@ -143,7 +143,7 @@ def test_propagate_to_ring_slot_equals_in_place(N, kernel):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4), (55, 2, 4), (66, 2, 3), (50, 3, 9), (47, 3, 2)])
+@pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4), (55, 2, 4), (66, 2, 3), (50, 3, 9), (47, 3, 2), (50, 5, 9), (48, 5, 3)])
 def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
     """viekf_batch_step_n: K IMU samples and the frame's updates in one launch (P stays on chip in the fused kernel) --
     bit for bit the K - 1 propagate calls + one step they replace; a forced negative depth makes a propagate's fix_depth

@@ -15,7 +15,7 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
-@pytest.mark.parametrize("N,kernel", [(6, 0), (50, 2), (30, 1), (60, 0), (70, 0), (50, 3)])
+@pytest.mark.parametrize("N,kernel", [(6, 0), (50, 2), (30, 1), (60, 0), (70, 0), (50, 3), (50, 5)])
 def test_masked_filters_are_untouched_and_the_others_unchanged(N, kernel):
     B, steps = 6, 2
     sc = scene.make_scene(B, N, steps, seed=9)

@@ -60,9 +60,9 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
     batch size -- it is otherwise chosen only for batches beyond one workgroup per CU --, 4 on-chip without the tile family"""
     from vi_ekf_amd import capi
     g = v.BatchVIEKF(B, N, sc["params"])
-    if kernel == 3:
-        g.set_tuning(capi.TUNE_TILES, 2)
-        assert "k_step_tiles" in g.describe(), g.describe()
+    if kernel in (3, 5):        # 3: one filter per workgroup, 5: the paired form (two filters per workgroup, the automatic choice for
+        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)        # batches beyond one filter per CU)
+        assert ("k_step_tiles_pair" if kernel == 5 else "k_step_tiles<") in g.describe(), g.describe()
     elif kernel == 4:
         g.set_tuning(capi.TUNE_TILES, 0)
         g.set_kernel(2)
@@ -81,6 +81,9 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
                                               (2, 33, 2, 2), (2, 41, 2, 2), (2, 49, 2, 2), (3, 50, 2, 2),
                                               # the tile family (P as fp64-MFMA accumulator tiles; NT = 11 tiles per side: N = 46 .. 50)
                                               (3, 50, 3, 3), (2, 46, 2, 3), (2, 47, 2, 3), (2, 48, 1, 3), (2, 49, 2, 3),
+                                              # ... its paired form (two filters per workgroup half a phase out of step; an odd batch
+                                              # leaves the last workgroup one filter)
+                                              (3, 50, 3, 5), (4, 46, 2, 5), (1, 47, 2, 5), (2, 48, 1, 5), (5, 49, 2, 5),
                                               # N + 14 > 64 lanes: the body lanes on a second service wave (<6,6>, two service waves)
                                               (3, 51, 2, 2), (2, 57, 2, 2), (2, 64, 2, 2), (2, 60, 2, 0), (2, 63, 2, 2), (2, 59, 1, 2),
                                               # more than 64 features: features 64.. on the body wave's lanes (<7,6>, N <= 72)
@@ -101,7 +104,7 @@ def test_step_parity(B, N, steps, kernel):
     assert (g.get_status() & 1 == 0).all()
 
 
-@pytest.mark.parametrize("N,kernel", [(12, 2), (50, 2), (57, 2), (30, 1), (70, 0), (50, 3), (47, 3)])
+@pytest.mark.parametrize("N,kernel", [(12, 2), (50, 2), (57, 2), (30, 1), (70, 0), (50, 3), (47, 3), (50, 5)])
 def test_general_lambda_on_the_bearing_components(N, kernel):
     """lambda_feat with entries != 1 on the bearing components: the fused kernel's general-Lambda instances (the reference's
     parameter files keep those at 1, which the ZU instances exploit; vi_ekf_meas.cpp:250-257)"""
@@ -130,7 +133,7 @@ def test_init_state_matches_oracle():
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P after init_feature")
 
 
-@pytest.mark.parametrize("N,nfeat,kernel", [(6, 4, 0), (12, 7, 0), (26, 20, 0), (50, 33, 3), (48, 48, 3), (46, 1, 3)])
+@pytest.mark.parametrize("N,nfeat,kernel", [(6, 4, 0), (12, 7, 0), (26, 20, 0), (50, 33, 3), (48, 48, 3), (46, 1, 3), (50, 33, 5), (47, 0, 5)])
 def test_propagate_only_partial_features_and_qx(N, nfeat, kernel):
     """inactive slots still receive Qx_feat (reference vi_ekf.cpp:139-144,304); drag term off; Qx != 0"""
     B = 3
@@ -151,7 +154,7 @@ def test_propagate_only_partial_features_and_qx(N, nfeat, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2), (76, 2), (50, 3), (46, 3)])
+@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2), (76, 2), (50, 3), (46, 3), (50, 5), (46, 5)])
 def test_update_gating_nan_invalid_and_full_update(N, kernel):
     """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update; both kernel
     families (the grouped streaming update has its own gate / skip paths inside a group)"""
@@ -192,7 +195,7 @@ def test_update_gating_nan_invalid_and_full_update(N, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2), (68, 2), (50, 3), (47, 3)])
+@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2), (68, 2), (50, 3), (47, 3), (50, 5)])
 def test_fix_depth_inside_the_updates(N, kernel):
     """fix_depth after an UPDATE (vi_ekf_meas.cpp:271): features that start just in front of the camera's infinity with a
     large depth variance correlated with the bearing are pushed to rho < 0 by noisy pixels -- the reset, the P(rho,rho) edit and the flag, in the middle
@@ -323,7 +326,7 @@ def test_wide_p_streaming_family(N, M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2), (66, 90, 2), (50, 130, 3)])
+@pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2), (66, 90, 2), (50, 130, 3), (50, 130, 5)])
 def test_more_measurements_than_one_launch_holds(N, M, kernel):
     """M > 64 measurements per step (the fused kernel takes 64 per launch: vi_ekf_amd chunks, P makes one extra HBM round
     trip per chunk), with repeated and skipped (-1) slots, against the oracle applying them one by one"""
@@ -354,7 +357,7 @@ def test_more_measurements_than_one_launch_holds(N, M, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,steps,kernel", [(12, 400, 1), (12, 400, 2), (50, 120, 2), (70, 60, 2), (50, 120, 3)])
+@pytest.mark.parametrize("N,steps,kernel", [(12, 400, 1), (12, 400, 2), (50, 120, 2), (70, 60, 2), (50, 120, 3), (50, 120, 5)])
 def test_long_run_stays_at_parity_and_symmetric(N, steps, kernel):
     """hundreds of steps (20 k updates at N=50..12): the covariance stays symmetric bit for bit and the distance to the oracle
     does not grow beyond the rounding level (the rank-2 update form amplifies any asymmetry of P -- DESIGN section 3 -- which a

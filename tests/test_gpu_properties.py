@@ -158,7 +158,7 @@ def test_device_hooks_equal_the_oracle_on_every_model(drag):
         assert_close(xp, g.x, "reset state"); assert_close(Nm, g.A, "reset Jacobian")
 
 
-@pytest.mark.parametrize("N,kernel", [(6, 1), (12, 0), (50, 0), (50, 3)])
+@pytest.mark.parametrize("N,kernel", [(6, 1), (12, 0), (50, 0), (50, 3), (50, 5)])
 def test_drag_term_switch_at_run_time(N, kernel):
     """vi_ekf_ros starts with the drag term OFF and turns it ON after take-off (src/vi_ekf_ros.cpp:86,428-429): steps before and
     after the switch against the oracle doing the same"""

@@ -15,7 +15,10 @@ def _params(seed, identity_qbu=False):
     return p
 
 
-def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64, log_root=None, log_filter=0):
+def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64, log_root=None, log_filter=0, frames=False,
+         want_gated=True):
+    """frames=True: every camera frame goes in through ONE viekf_seq_add_frame call (one queue entry per frame) instead of one
+    add_measurement per feature; want_gated=False: handle_measurements() without the optional list (nothing waited for)"""
     import vi_ekf_amd as v
     p = _params(seed, identity_qbu)
     g = v.BatchVIEKF(B, N, dict(p, keyframe_overlap_threshold=0.8, name="seq"))
@@ -37,21 +40,27 @@ def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=
             os_[b].propagate_state(u[b], t)
         if k % 7 == 3:   # a camera frame, time-stamped `delay` seconds ago: FEAT for every feature + an altimeter reading
             tz = t - delay
+            zf = np.zeros((B, N, 2))
             for i in range(N):
                 z = pix[:, i, :] + rng.normal(0, 0.5, (B, 2))
                 if nan_filter is not None and i == 1 and k > 20:
                     z[nan_filter, 0] = np.nan
-                rg = sg.add_measurement(tz, z, orc.FEAT, R, True, id=i)
+                zf[:, i, :] = z
+                rg = None if frames else sg.add_measurement(tz, z, orc.FEAT, R, True, id=i)
                 for b in range(B):
                     ro = os_[b].add_measurement(tz, z[b], orc.FEAT, R, True, i, float("nan"))
-                    assert rg[b] == ro, (k, i, b, rg[b], ro)
+                    assert frames or rg[b] == ro, (k, i, b, rg[b], ro)
+            if frames:
+                rf = sg.add_frame(tz, zf, R, np.arange(N))
+                assert rf.shape == (B, N)
             alt = rng.normal(2.0, 0.05, (B, 1))
             sg.add_measurement(tz + 0.001, alt, orc.ALT, np.array([[0.01]]), True)
             for b in range(B):
                 os_[b].add_measurement(tz + 0.001, alt[b], orc.ALT, np.array([[0.01]]), True)
-            gg = sg.handle_measurements()
+            gg = sg.handle_measurements(want_gated=want_gated)
             for b in range(B):
-                gated_g[b] += gg[b]
+                if want_gated:
+                    gated_g[b] += gg[b]
                 gated_o[b] += os_[b].handle_measurements()
     return g, sg, os_, gated_g, gated_o
 
@@ -72,6 +81,24 @@ def test_sequencer_matches_reference_plumbing(delay):
     st = sg.status()
     assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
     assert st["queued"] == len(os_[0].zbuf) and st["inputs"] == len(os_[0].u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delay,want_gated", [(0.0, True), (0.0105, True), (0.03, True), (0.03, False)])
+def test_whole_frames_in_one_call_equal_one_call_per_feature(delay, want_gated):
+    """viekf_seq_add_frame queues a camera frame as ONE entry: bit for bit the filter that was fed one add_measurement per feature
+    (same launches, same order), the restated reference plumbing to the parity tolerance, the same gated ids; a NaN pixel of one
+    filter skips that filter's entry only.  want_gated=False: handle_measurements without the list waits for nothing."""
+    B, N = 3, 6
+    # (q_b_u = identity: a filter that skips an entry still takes part in the others' replays, which is exact only then)
+    ga, sa, os_, gga, go = _run(B, N, seed=3, delay=delay, nan_filter=2, identity_qbu=True)
+    gb, sb, _, ggb, _ = _run(B, N, seed=3, delay=delay, nan_filter=2, identity_qbu=True, frames=True, want_gated=want_gated)
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+    assert sa.tracked_features() == sb.tracked_features()
+    if want_gated:
+        assert gga == ggb == go
+    assert_close(gb.get_state(), np.stack([o.f.x for o in os_]), "x")
+    assert_close(gb.get_covariance(), np.stack([o.f.P for o in os_]), "P")
 
 
 @pytest.mark.gpu

@@ -20,8 +20,8 @@ def main():
     sc = scene.make_scene(B, N, 4, seed=3)
     g = v.BatchVIEKF(B, N, sc["params"])
     from vi_ekf_amd import capi
-    if kernel == 3:      # the tile family whatever the batch size
-        g.set_tuning(capi.TUNE_TILES, 2)
+    if kernel in (3, 5):      # the tile family whatever the batch size: 3 one filter per workgroup, 5 the paired form
+        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)
     elif kernel == 4:    # the on-chip families without the tile family
         g.set_tuning(capi.TUNE_TILES, 0)
     elif kernel:

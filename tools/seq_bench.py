@@ -46,7 +46,7 @@ def run(B=1024, N=50, independent=False, frames=12, per_feature=False, delay=0.0
                     s.add_measurement(stamp, zf[:, i, :], 6, R, True, int(i))
             else:
                 s.add_frame(stamp, zf, R, ids)
-            s.handle_measurements()
+            s.handle_measurements(want_gated=False)
             nframes += 1
             if nframes == 2:          # warm-up done
                 g.sync()

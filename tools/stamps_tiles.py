@@ -16,7 +16,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 sc = scene.make_scene(B, N, 3, seed=3)
 g = v.BatchVIEKF(B, N, sc["params"])
-g.set_tuning(capi.TUNE_TILES, 2)
+g.set_tuning(capi.TUNE_TILES, int(sys.argv[3]) if len(sys.argv) > 3 else 3)
 print(g.describe())
 for i in range(N):
     g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))

@@ -497,15 +497,19 @@ res_kernel_t res_kernel(int inst, bool multi = false, bool zu = false) {
 }
 
 // Tile family instances <NT, NW>: NT tiles per side (an instance runs the feature counts with 1 + ceil(N / 5) == NT: its
-// tile -> wave map is compile-time), NW worker waves + 1 service wave (N + 14 <= 64 lanes).
-struct TileInst { int NT, NW, max_lds_kb; };
+// tile -> wave map is compile-time), NW worker waves + 1 service wave (N + 14 <= 64 lanes).  pair: TWO filters per 512-thread
+// workgroup, one workgroup per CU, their update loops half a phase out of step (k_step_tiles_pair) -- the form for batches
+// beyond one filter per CU; the single form is one filter per 256-thread workgroup.
+struct TileInst { int NT, NW, max_lds_kb, pair; };
 const TileInst kTileInst[] = {
-    {11, 3, 80},   // N = 46 .. 50: two 256-thread workgroups per CU (B > #CUs): the headline instance
+    {11, 3, 160, 1},   // N = 46 .. 50, pairs: the headline instance
+    {11, 3, 80, 0},    // N = 46 .. 50, one filter per workgroup
 };
 
 res_kernel_t tile_kernel(int inst, bool multi) {
   switch (inst) {
-    case 0: return multi ? k_step_tiles<11, 3, true> : k_step_tiles<11, 3, false>;
+    case 0: return multi ? k_step_tiles_pair<11, true> : k_step_tiles_pair<11, false>;
+    case 1: return multi ? k_step_tiles<11, 3, true> : k_step_tiles<11, 3, false>;
   }
   return nullptr;
 }
@@ -514,17 +518,19 @@ int setup_tiles(viekf_batch* b) {
   b->tile_inst = -1;
   if (!b->tune_tiles || b->N + 14 > 64 || b->N < 1) return VIEKF_OK;
   const int NT = 1 + (b->N + 4) / 5;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
   for (int i = 0; i < (int)(sizeof(kTileInst) / sizeof(kTileInst[0])); i++) {
     const TileInst& r = kTileInst[i];
     if (r.NT != NT || 16 * NT > 64 * r.NW) continue;   // (one worker thread per tile-space row brings the next column pair up to date)
+    // tune_tiles: 1 automatic (pairs once the batch exceeds one filter per CU, nothing below that: the resident family's
+    // one-workgroup-per-CU instances run small batches), 2 the single form, 3 the paired form -- whatever the batch size
+    if (b->tune_tiles == 1 && !(r.pair && b->B > cus)) continue;
+    if (b->tune_tiles == 2 && r.pair) continue;
+    if (b->tune_tiles == 3 && !r.pair) continue;
     const TileLds L(b->N, b->n, b->nxs);
-    const size_t lds = sizeof(double) * (size_t)L.total;
+    const size_t lds = sizeof(double) * (size_t)L.total * (r.pair ? 2 : 1);
     if (lds > (size_t)r.max_lds_kb * 1024) continue;
-    if (r.max_lds_kb <= 80 && b->tune_tiles != 2) {   // two workgroups per CU only pay when the batch fills the CUs more than once
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
-      if (b->B <= cus) continue;
-    }
     {
       std::lock_guard<std::mutex> lk(g_attr_mutex);
       static size_t have[64][sizeof(kTileInst) / sizeof(kTileInst[0])] = {};
@@ -609,13 +615,15 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
   const bool tiles = use_tiles(b);
   const res_kernel_t kern = tiles ? tile_kernel(b->tile_inst, KP > 1) : res_kernel(b->res_inst, KP > 1, b->res_zu);
-  const int threads = tiles ? (kTileInst[b->tile_inst].NW + 1) * 64 : (kResInst[b->res_inst].NW + kResInst[b->res_inst].NS) * 64;
+  const bool pair = tiles && kTileInst[b->tile_inst].pair;
+  const int threads = tiles ? (pair ? 512 : (kTileInst[b->tile_inst].NW + 1) * 64) : (kResInst[b->res_inst].NW + kResInst[b->res_inst].NS) * 64;
+  const unsigned grid = pair ? (unsigned)((b->B + 1) / 2) : (unsigned)b->B;
   const size_t lds = tiles ? b->tile_lds : b->res_lds;
   int m0 = 0;
   do {
     const int cap = res_mcap(b->N);
     const int mc = (M - m0 < cap) ? (M - m0) : cap;
-    hipLaunchKernelGGL(kern, dim3(b->B), dim3(threads), lds, b->stream, a,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, b->stream, a,
                        ((do_prop && m0 == 0) ? (1 | (KP << 16)) : 0) | ((dbg_bits() & 0xff) << 8), d_u, d_dt, d_z ? d_z + 2L * m0 : nullptr,
                        d_slot ? d_slot + m0 : nullptr, mc, M, d_R ? d_R + rsm * m0 : nullptr, rsb, rsm,
                        d_res ? d_res + m0 : nullptr);
@@ -828,8 +836,10 @@ int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
   char buf[256];
   if (use_tiles(b)) {
     const TileInst& r = kTileInst[b->tile_inst];
-    snprintf(buf, sizeof buf, "k_step_tiles<%d,%d>: P as %d 16x16 fp64-MFMA accumulator tiles on %d worker waves + 1 service wave, %s per CU (LDS %zu KB)",
-             r.NT, r.NW, r.NT * (r.NT + 1) / 2, r.NW, r.max_lds_kb <= 80 ? "2 workgroups" : "1 workgroup", b->tile_lds / 1024);
+    snprintf(buf, sizeof buf, "%s<%d>: P as %d 16x16 fp64-MFMA accumulator tiles on %d worker waves + 1 service wave per filter, %s (LDS %zu KB)",
+             r.pair ? "k_step_tiles_pair" : "k_step_tiles", r.NT, r.NT * (r.NT + 1) / 2, r.NW,
+             r.pair ? "two filters per 512-thread workgroup half a phase out of step, one workgroup per CU" : "one filter per 256-thread workgroup, 2 workgroups per CU",
+             b->tile_lds / 1024);
   } else if (use_resident(b)) {
     const ResInst& r = kResInst[b->res_inst];
     snprintf(buf, sizeof buf, "k_step_resident<%d,%d>%s: %d worker waves x %d blocks + %d service wave%s, %s per CU (LDS %zu KB)",
@@ -905,7 +915,7 @@ int viekf_batch_set_tuning(viekf_batch* b, int32_t key, int32_t value) {
       b->tune_block_group = value;
       return VIEKF_OK;
     case VIEKF_TUNE_TILES:
-      if (value < 0 || value > 2) return fail(VIEKF_ERR_INVALID, "tile family: 0 off, 1 automatic, 2 whatever the batch size");
+      if (value < 0 || value > 3) return fail(VIEKF_ERR_INVALID, "tile family: 0 off, 1 automatic, 2 single form, 3 paired form");
       b->tune_tiles = value;
       HIP_TRY(hipStreamSynchronize(b->stream));
       return setup_tiles(b);

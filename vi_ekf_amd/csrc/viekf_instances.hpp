@@ -30,4 +30,6 @@
   PFX template __global__ void viekf::k_step_resident<RB, NW, true, NS, true>(VIEKF_STEP_ARGS);
 #define VIEKF_TILE_FLAVOURS(PFX, NT, NW)                                              \
   PFX template __global__ void viekf::k_step_tiles<NT, NW, false>(VIEKF_STEP_ARGS);  \
-  PFX template __global__ void viekf::k_step_tiles<NT, NW, true>(VIEKF_STEP_ARGS);
+  PFX template __global__ void viekf::k_step_tiles<NT, NW, true>(VIEKF_STEP_ARGS);   \
+  PFX template __global__ void viekf::k_step_tiles_pair<NT, false>(VIEKF_STEP_ARGS); \
+  PFX template __global__ void viekf::k_step_tiles_pair<NT, true>(VIEKF_STEP_ARGS);

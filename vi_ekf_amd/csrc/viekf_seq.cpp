@@ -29,6 +29,11 @@ struct SeqMeas {                      // measurement_t, include/vi_ekf.h:167-179
   std::vector<int32_t> id;            // [B] global feature id
   std::vector<uint8_t> present;       // [B] this filter queued the entry
   bool handled;
+  // count > 1: a whole camera frame queued by viekf_seq_add_frame as ONE entry -- `count` FEAT measurements with the same stamp
+  // and R, z [B][count][2], id / present [B][count], stored in the order handle_measurements consumes same-stamp entries (the
+  // reverse of their insertion, vi_ekf_meas.cpp:150-176 with :16-18,96-98).  A later entry with the same stamp is inserted behind
+  // every earlier one (:150-156), never between two of them, so the block is what its `count` separate entries would be.
+  int count = 1;
 };
 
 void rota(const double* q, const double* v, double* o) {   // src/quat.cpp:279-283
@@ -294,7 +299,7 @@ int update_entry(viekf_seq* s, SeqMeas& m, std::vector<int32_t>& res) {   // VIE
 
 // entries of one camera frame: unhandled active FEAT measurements with the same time stamp and the same R
 bool frame_mate(const SeqMeas& a, const SeqMeas& z) {
-  return !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim && a.R == z.R;
+  return a.count == 1 && !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim && a.R == z.R;
 }
 
 // the k entries zbuf[zi], zbuf[zi-1], ..., zbuf[zi-k+1] (the order handle_measurements visits them) as one launch;
@@ -314,6 +319,21 @@ int update_frame(viekf_seq* s, long zi, int k, std::vector<int32_t>& res) {
   }
   res.assign((size_t)B * k, VIEKF_MEAS_SKIPPED);
   return viekf_batch_update_feat(s->core, z.data(), slot.data(), k, s->zbuf[zi].R.data(), 0, res.data(), VIEKF_HOST);
+}
+
+// a frame block (SeqMeas::count > 1) as one launch; res [B][count] (NULL: nobody asked for the result codes -- the launch is then
+// queued without waiting for it)
+int update_block(viekf_seq* s, SeqMeas& m, std::vector<int32_t>* res) {
+  const int B = s->B, k = m.count;
+  m.handled = true;                                                // :198
+  std::vector<int32_t> slot((size_t)B * k, -1);
+  for (int b = 0; b < B; b++)
+    for (int j = 0; j < k; j++) {
+      const size_t e = (size_t)b * k + j;
+      slot[e] = m.present[e] ? local_id(s, b, m.id[e]) : -1;
+    }
+  if (res) res->assign((size_t)B * k, VIEKF_MEAS_SKIPPED);
+  return viekf_batch_update_feat(s->core, m.z.data(), slot.data(), k, m.R.data(), 0, res ? res->data() : nullptr, VIEKF_HOST);
 }
 
 // ---- independent clocks --------------------------------------------------------------------------------------------------
@@ -751,6 +771,57 @@ int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int3
   if (!s || !z || !R || !id || count < 0) return VIEKF_ERR_INVALID;
   if (t_per_filter && !s->indep) return VIEKF_ERR_INVALID;
   const int B = s->B;
+  if (!s->indep && s->log.empty() && active && count > 1) {
+    // shared clock, no log writer: ONE queue entry for the frame (SeqMeas::count).  Per feature k = 0 .. count - 1, in order, the
+    // tests of add_measurement (vi_ekf_meas.cpp:133-147): before the start, NaN, an unknown id starts a feature at the CURRENT state
+    SeqMeas m;
+    m.t = t; m.type = VIEKF_FEAT; m.zdim = 2; m.rdim = 2; m.active = true; m.handled = false; m.count = count;
+    m.R.assign(R, R + 4);
+    m.z.assign((size_t)B * count * 2, 0.0);
+    m.id.assign((size_t)B * count, -1);
+    m.present.assign((size_t)B * count, 0);
+    bool any_present = false;
+    std::vector<uint8_t> newf(B);
+    std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
+    std::vector<int32_t> ok(B);
+    for (int k = 0; k < count; k++) {
+      const int j = count - 1 - k;                                 // position in processing order (last added is consumed first)
+      bool any_new = false;
+      for (int b = 0; b < B; b++) {
+        const size_t e = (size_t)b * count + k, o = (size_t)b * count + j;
+        int32_t r = VIEKF_MEAS_SUCCESS;
+        newf[b] = 0;
+        if (t < s->start_t) r = VIEKF_MEAS_INVALID;                                   // :133-134
+        else if (std::isnan(z[2 * e]) || std::isnan(z[2 * e + 1])) r = VIEKF_MEAS_NAN;   // :136-137
+        else if (id[e] >= 0 && local_id(s, b, id[e]) < 0) {                            // :140-147
+          r = VIEKF_MEAS_NEW_FEATURE;
+          if ((int)s->ids[b].size() < s->N) { newf[b] = 1; any_new = true; }          // vi_ekf_feat.cpp:9-10
+        } else {
+          m.present[o] = 1;
+          any_present = true;
+        }
+        m.z[2 * o] = z[2 * e]; m.z[2 * o + 1] = z[2 * e + 1];
+        m.id[o] = id[e];
+        if (result) result[e] = r;
+      }
+      if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
+        for (int b = 0; b < B; b++) {
+          const size_t e = (size_t)b * count + k;
+          zk[2 * (size_t)b] = z[2 * e]; zk[2 * (size_t)b + 1] = z[2 * e + 1];
+          dk[b] = depth ? depth[e] : NAN;
+        }
+        if (int rc = viekf_batch_init_feature(s->core, zk.data(), dk.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
+        for (int b = 0; b < B; b++)
+          if (newf[b] && ok[b]) push_feature(s, b);
+      }
+    }
+    if (any_present) {
+      size_t k = 0;                                                                    // :150-156
+      while (k < s->zbuf.size() && !(s->zbuf[k].t < t)) k++;
+      s->zbuf.insert(s->zbuf.begin() + (long)k, std::move(m));                         // :169-175
+    }
+    return VIEKF_OK;
+  }
   std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
   std::vector<int32_t> ik(B), rk(B);
   for (int k = 0; k < count; k++) {
@@ -808,6 +879,7 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     if (int rc = run_ops(s, ops, gated)) return rc;
     return finish();
   }
+  const bool want_gated = gated_ids != nullptr || gated_count != nullptr;   // (nobody asked: the frame's launch is not waited for)
   if (s->zbuf.empty() || s->u.empty()) return finish();            // :12-13
   long zi = (long)s->zbuf.size() - 1;                              // :16-18 oldest unhandled
   while (s->zbuf[zi].handled && zi != 0) zi--;
@@ -847,9 +919,16 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
         // as ONE launch of M sequential updates -- the same arithmetic, P crosses HBM once per frame instead of once per
         // feature.  (Not while logging: the log wants zhat before every single update.)
         long zl = zi;
-        if (s->log.empty() && z.type == VIEKF_FEAT && z.active)
+        if (s->log.empty() && z.type == VIEKF_FEAT && z.active && z.count == 1)
           while (zl > 0 && frame_mate(s->zbuf[zl - 1], z)) zl--;
-        if (zl < zi) {
+        if (z.count > 1) {
+          std::vector<int32_t> resk;
+          if (int rc = update_block(s, z, want_gated ? &resk : nullptr)) return rc;
+          if (want_gated)
+            for (int j = 0; j < z.count; j++)
+              for (int b = 0; b < B; b++)
+                if (resk[(size_t)b * z.count + j] == VIEKF_MEAS_GATED) gated[b].push_back(z.id[(size_t)b * z.count + j]);
+        } else if (zl < zi) {
           const int k = (int)(zi - zl + 1);
           std::vector<int32_t> resk;
           if (int rc = update_frame(s, zi, k, resk)) return rc;
@@ -882,7 +961,11 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     if (!left_inner_by_break) break;   // (the inner condition can only fail with ui == 0)
   }
   if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;   // :118
-  while ((int)s->zbuf.size() > s->MH) s->zbuf.pop_back();          // :121-122
+  {   // :121-122 (the reference counts measurements: a frame block weighs its `count`)
+    long total = 0;
+    for (const auto& e : s->zbuf) total += e.count;
+    while (total > s->MH && !s->zbuf.empty()) { total -= s->zbuf.back().count; s->zbuf.pop_back(); }
+  }
   while ((int)s->u.size() > s->H) s->u.pop_back();                 // :125-126
   return finish();
 }

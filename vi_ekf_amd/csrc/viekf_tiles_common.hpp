@@ -80,13 +80,14 @@ __device__ __forceinline__ double tile_mu(const double* lam, int q, int nf, bool
 __device__ __forceinline__ int tile_qrow(int f, int r) { return 16 * (1 + f / 5) + 3 * (f % 5) + r; }
 
 // Common prologue: LDS carve-up, state, lambdas, mailboxes and the measurement table (validity decided once, here).
+// T = number of threads that run it for this filter (tid = 0 .. T - 1), b = the filter.  present = false: a workgroup of the paired
+// kernel whose second filter does not exist (odd batch) or takes no part (participation mask): only the barriers and the count.
 template <int T>
-__device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S, double* smem, int do_prop,
+__device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S, double* smem, int b, int tid, bool present, int do_prop,
                                               const double* __restrict__ dt_all, const double* __restrict__ z_all,
                                               const int* __restrict__ slot_all, int M, int m_stride,
                                               const double* __restrict__ R_all, long r_stride_b, long r_stride_m,
                                               int* __restrict__ result_all) {
-  const int b = blockIdx.x, tid = threadIdx.x;
   const TileLds L(a.N, a.n, a.nxs);
   S.xs = smem + L.xs; S.lam = smem + L.lam; S.sm = smem + L.sm; S.fixadd = smem + L.fixadd; S.fixset = smem + L.fixset;
   S.Z = smem + L.Z; S.phiff = smem + L.phiff; S.Abb = smem + L.Abb; S.Gb = smem + L.Gb; S.Phibb = smem + L.Phibb; S.Mbb = smem + L.Mbb;
@@ -98,10 +99,10 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
   S.mslot = reinterpret_cast<int*>(smem + L.mslot);
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
-  S.N = a.N; S.mcap = res_mcap(a.N); S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1;
+  S.N = a.N; S.mcap = res_mcap(a.N); S.n = a.n; S.nf = 3 * a.N; S.len = present ? a.len[b] : 0; S.M = present ? M : 0; S.mstride = m_stride; S.do_prop = do_prop & 1;
   S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
   S.NT = tile_nt(a.N); S.NQ = 16 * S.NT;
-  {
+  if (present) {
     const double* xg = a.x + (long)b * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
@@ -122,10 +123,15 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
     }
   }
   __syncthreads();
-  for (int mm_ = tid; mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= res_mcap(N))
+  for (int mm_ = tid; present && mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= res_mcap(N))
     int nx = mm_ + 1;
     while (nx < M && S.mslot[nx] < 0) nx++;
     S.mseq[mm_] = make_int2(nx, nx < M ? S.mslot[nx] : -1);
+  }
+  if (tid == 0) {   // number of updates that will run (the paired kernel's two filters loop in step: the longer count rules)
+    int c = 0;
+    for (int i = 0; present && i < M; i++) c += S.mslot[i] >= 0;
+    S.sm[60] = (double)c;
   }
   __syncthreads();
 }

@@ -11,9 +11,9 @@ namespace viekf {
 //     never formed (vi_ekf_meas.cpp:241,249-255),
 //   keeps each feature's zeta-zeta 2x2 of P current:  P_zz -= Lambda o (C_z G C_z^T),
 //   runs fix_depth, predicts measurement m+1 on the lane of its feature and publishes its  G = Hb^T S^-1 Hb  and verdict.
-template <int T, bool MP>
+template <int T, bool MP, bool PAIR = false>
 __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShared& S, int lane, const double* __restrict__ u_all,
-                                             const double* __restrict__ dt_all, int* __restrict__ result_all) {
+                                             const double* __restrict__ dt_all, int* __restrict__ result_all, int half = 0, int trips = 0) {
   const int N = S.N, len = S.len, M = S.M, NQ = S.NQ;
   const DevParams& prm = *a.dp;
   double* xs = S.xs;
@@ -171,7 +171,10 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
   RES_STAMP(S, lane == 0, 5);
   int cnt = 0;
 
-  while (m < M) {
+  if (PAIR && half) __syncthreads();   // (filter 1 of a pair runs half a phase behind: viekf_tiles_worker.hpp)
+  const int ntrip = PAIR ? trips : 0x7fffffff;
+  for (int trip = 0; trip < ntrip && (PAIR || m < M); trip++) {
+    if (PAIR && m >= M) { __syncthreads(); __syncthreads(); continue; }
     const int mnext = __builtin_amdgcn_readfirstlane(sq.x), slot_next = __builtin_amdgcn_readfirstlane(sq.y);
     sq = S.mseq[min(mnext, S.mcap - 1)];
     const double* Cc = S.Cb + (cnt & 1) * 2 * NQ;
@@ -211,6 +214,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
       pf11 = fma(-L11, fma(k11, c1.y, k10 * c1.x), pf11);
     }
     RES_STAMP(S, lane == 0 && cnt < 8, 16 + 4 * cnt + 1);
+    if (PAIR) __syncthreads();   // mid-phase barrier of the pair (no data of this wave's depends on it)
     if (lane == 0) sm[40 + par] = 0.0;
     // fix_depth (vi_ekf_meas.cpp:271; a gated update returns before it, :238): almost never fires -- one wave-wide test
     const bool odd_depth = !gated && isfeat && fid < len && !(lin >= 0.0 && lin <= 1e2);
@@ -245,6 +249,7 @@ __device__ __forceinline__ void tile_service(const StreamArgs& a, const TileShar
     RES_STAMP(S, lane == 0 && cnt <= 8, 16 + 4 * (cnt - 1) + 3);
     m = mnext;
   }
+  if (PAIR && !half) __syncthreads();
 
   RES_STAMP(S, lane == 0, 12);
   if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }

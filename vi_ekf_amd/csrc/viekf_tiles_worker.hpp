@@ -54,8 +54,14 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // A tile register X[r] holds P[prow(TI, l & 15)][prow(TJ, (l >> 4) + 4 r)]: D's column index j runs along the ROWS of P inside
 // tile row TI, D's row index i along the columns inside tile column TJ.  So the A operand carries the TJ-side factor and the
 // B operand the TI-side factor, both indexed by l & 15, component k = l >> 4.
-template <int NT, int NW, int W, bool MP>
-__device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShared& S, int tid) {
+// PAIR: two filters share a 512-thread workgroup (k_step_tiles_pair) and run their update loops HALF A PHASE out of step: every
+// update has two barriers -- [operands, MFMAs, next column pair] | [extraction] -- and filter 1 (half = 1) starts one barrier late,
+// so one filter's matrix instructions run beside the other's extraction and scalar work on every SIMD they share.  (Two
+// independent workgroups per CU fall into step instead: their MFMA bursts collide on the SIMD's one matrix pipe, then both
+// extract while it idles -- measured 5,500 clocks per update pair against 2 x 1,408 of matrix work.)  trips = updates the longer
+// of the two filters runs (both loop that often; a filter that is done idles through the barriers).
+template <int NT, int NW, int W, bool MP, bool PAIR = false>
+__device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShared& S, int tid, int half = 0, int trips = 0) {
   typedef TileMap<NT, NW> Map;
   constexpr int TW = NW * 64, TPW = Map::max_count(), CNT = Map::count(W);
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len, NQ = S.NQ;
@@ -335,7 +341,10 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   // (I-KH)P(I-KH)^T + KRK^T - P restricted by Lambda, vi_ekf_meas.cpp:254-257, for K = C Hb^T S^-1), (2) bring the NEXT
   // measurement's raw column pair -- extracted one phase ago, before this update -- up to date with this update (one row per
   // thread), (3) extract the raw column pair of the measurement after next from the swept tiles.
-  while (m < S.M) {
+  if (PAIR && half) __syncthreads();   // (filter 1 runs half a phase behind)
+  const int ntrip = PAIR ? trips : 0x7fffffff;
+  for (int trip = 0; trip < ntrip && (PAIR || m < S.M); trip++) {
+    if (PAIR && m >= S.M) { __syncthreads(); __syncthreads(); continue; }   // (done: keeps the other filter's barriers company)
     const int mnext = sq.x, snext = sq.y;
     const int2 sq2 = uni2(S.mseq[min(mnext, S.mcap - 1)]);
     const double* mb = S.sm + 8 * (cnt & 1);
@@ -404,6 +413,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     }
     RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 1);
     RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 2);
+    if (PAIR) __syncthreads();   // mid-phase: from here the other filter of the pair has the matrix pipe
     // (3) raw column pair of the measurement after next, from the swept tiles
     if (sq2.y >= 0 && mnext < S.M && !RES_ABLATE(S, 4)) extract(sq2.y, S.Eb + (cnt & 1) * 2 * NQ);
     RES_STAMP(S, st0 && cnt < 8, 80 + 4 * cnt + 3);
@@ -414,6 +424,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     RES_STAMP(S, st0 && cnt <= 8, 112 + cnt - 1);
     m = mnext;
   }
+  if (PAIR && !half) __syncthreads();
   apply_fixes(par ^ 1, S.sm[40 + (par ^ 1)]);
   RES_STAMP(S, st0, 74);
 

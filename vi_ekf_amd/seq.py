@@ -118,7 +118,12 @@ class SeqVIEKF:
                                                None if da is None else _p(da), None if mk is None else _p(mk), _p(res)))
         return res
 
-    def handle_measurements(self, cap=64):
+    def handle_measurements(self, cap=64, want_gated=True):
+        """want_gated=False = the reference's handle_measurements() without the optional list (test/vi_ekf_test.cpp:32): the frame's
+        launch is then queued, not waited for"""
+        if not want_gated:
+            capi.check(self._L.viekf_seq_handle_measurements(self._h, None, 0, None))
+            return None
         ids = np.full((self.B, cap), -1, dtype=np.int32)
         cnt = np.zeros(self.B, dtype=np.int32)
         capi.check(self._L.viekf_seq_handle_measurements(self._h, _p(ids), cap, _p(cnt)))
