@@ -74,6 +74,35 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """host threads this process may really use: the scheduler affinity, capped by a cgroup CPU quota if one is set (a GPU box
+    hands a one-GPU job a share of the host, not all of it) -> (threads, how it was determined)"""
+    n = os.cpu_count() or 1
+    how = "os.cpu_count()"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, how = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    q = int(int(txt[0]) / int(txt[1]))
+                    if 0 < q < n:
+                        n, how = q, "cgroup cpu.max"
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0 and 0 < quota // period < n:
+                    n, how = quota // period, "cgroup cfs quota"
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n), how
+
+
 def oracle_run(sc, N, params, which, steps_cmp, threads, structured=False):
     """The oracle on filters `which` x `steps_cmp` steps of the SAME inputs -> (x, P, seconds).
     Checker / baseline only -- never the product path."""
@@ -153,6 +182,7 @@ def main():
     if args.kernel:
         g.set_kernel(args.kernel)
     g.use_torch_stream()
+    desc = g.describe()
     d_u = torch.tensor(sc["u"], device=dev)
     d_z = torch.tensor(sc["z"], device=dev)
     d_dt = torch.tensor(sc["dt"], device=dev)
@@ -180,8 +210,9 @@ def main():
         n = 16 + 3 * N
         flop = (8 + 4 * N) * float(n) ** 3      # dense cost per filter-step; ~6 GFLOP/s per thread for the plain-C loops
         if world == 1:
-            threads = min(ncpu, 16)
-            nf = args.cpu_filters or min(B, 8 * threads)
+            # SURVEY 8(d) / BASELINE.md 3: one filter per thread over ALL host cores this job may use (r02 capped this at 16)
+            threads, threads_how = usable_cpus()
+            nf = args.cpu_filters or min(B, 4 * threads)
             # ~10-15 s of CPU work for the all-core dense figure, capped by the distinct frames
             sc_steps = args.cpu_steps or int(max(1, min(uniq, round(12.0 * 6.0e9 * threads / (flop * nf)))))
         else:   # N > 1: every rank checks 8 of its own filters, sharing the host cores with the other ranks
@@ -200,7 +231,7 @@ def main():
             raise SystemExit("PARITY FAILURE vs oracle (rank %d): rel err %.3e" % (rank, parity))
         if rank == 0 and world == 1:
             cpu = {"value": len(which) * sc_steps / secs_d, "unit": "EKF steps/s", "cores": threads, "kind": "port",
-                   "cpu_model": cpu_model(), "host_cores": ncpu,
+                   "cpu_model": cpu_model(), "host_cores": ncpu, "cores_from": threads_how,
                    "sample": "%d filters (strided over the batch) x %d steps of the same inputs, dense reference-order oracle "
                              "(vi_ekf.cpp:301-304, vi_ekf_meas.cpp:232-257), %.1f s wall; extrapolates linearly to the batch"
                              % (len(which), sc_steps, secs_d)}
@@ -315,6 +346,19 @@ def main():
         except Exception as e:   # (a secondary number must never cost the primary one)
             single = {"error": str(e)[:200]}
 
+    # ... and the DROP-IN route: the same filters driven through viekf_seq_propagate / _add_frame /
+    # _handle_measurements at 250 Hz : 30 Hz with the camera's 30 ms delay -- every frame rewinds and replays (tools/seq_bench.py)
+    seq_cad = None
+    if world == 1 and not args.no_secondary:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import seq_bench
+            seq_cad = {"shared_clock": seq_bench.run(B, N, False, 10), "independent_clocks": seq_bench.run(B, N, True, 5)}
+            if cadence is not None:
+                seq_cad["shared_vs_raw_cadence"] = seq_cad["shared_clock"]["imu_steps_per_s"] / cadence["imu_steps_per_s"]
+        except Exception as e:
+            seq_cad = {"error": str(e)[:300]}
+
     # per-launch duration of the step's kernels from HIP events on the launch stream
     launch_ms = np.array([ev[i].elapsed_time(ev[i + 1]) / (marks[i + 1] - marks[i]) for i in range(len(ev) - 1)])
     launch_s = float(np.median(launch_ms)) * 1e-3   # (median over the groups of the groups' average launch duration)
@@ -353,9 +397,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("%s; one fused launch per step, median HIP-event duration per launch %.4f ms"
-                                    if g.describe().startswith("k_step_resident") else
+                                    if desc.startswith(("k_step_resident", "k_step_tiles")) else
                                     "%s; one propagate and one update launch per step, median HIP-event duration of the pair %.4f ms")
-                                   % (g.describe(), launch_s * 1e3),
+                                   % (desc, launch_s * 1e3),
                          "alg_bytes_per_launch": alg_bytes},
             "nan_filters": n_bad,
             "gated_frac": work["gated_frac"],
@@ -365,12 +409,22 @@ def main():
         # structured algorithmic flops of one step: Phi P Phi^T + G Q G^T + N rank-2 Lambda-masked sweeps
         n_ = 16 + 3 * N
         f_alg = 2 * 2 * n_ * (256 + 57 * N) + 12 * n_ * n_ + N * 6 * n_ * n_
+        # what the on-chip kernels EXECUTE: P is symmetric and one block / tile of every pair is held, so the sweeps and the
+        # propagate touch n (n + 1) / 2 elements -- roughly half the algorithmic count above, which prices the full matrix
+        f_exec = 2 * n_ * (256 + 57 * N) + 6 * n_ * n_ + N * 3 * n_ * (n_ + 1)
         out["flops"] = {"alg_flop_per_step": f_alg, "achieved_tflops": f_alg * B / launch_s / 1e12, "peak_tflops": 78.6,
-                        "frac": f_alg * B / launch_s / 1e12 / 78.6}
+                        "frac": f_alg * B / launch_s / 1e12 / 78.6,
+                        "executed_flop_per_step": f_exec, "executed_tflops": f_exec * B / launch_s / 1e12,
+                        "executed_frac": f_exec * B / launch_s / 1e12 / 78.6,
+                        "note": "frac prices the full n x n matrix (SURVEY 8d); the kernels hold and sweep the symmetric half: "
+                                "executed_frac is the pipe utilisation (vector fp64 measured at 6.4 clk per wave-FMA on this part, "
+                                "tools/micro/mfma_f64_rate.hip: the 78.6 TFLOP/s peak is the matrix cores')"}
         if cadence is not None:
             out["cadence_250_30"] = cadence
         if single is not None:
             out["single_filter_n12"] = single
+        if seq_cad is not None:
+            out["seq_cadence_250_30"] = seq_cad
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if not args.no_cpu_baseline:

@@ -132,9 +132,9 @@ int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
  *   VIEKF_TUNE_UNIT_LAMBDA   0 = never the instances specialised for lambda_feat = [1, 1, x]
  *   VIEKF_TUNE_BLOCK_GROUP   measurements per pass of the grouped wide-P update: 0 = automatic, 16, 24, 32 (used where it fits the LDS)
  *   VIEKF_TUNE_STREAM_MFMA   0 = the streaming kernels without matrix-core passes (one pass over P per measurement)
- *   VIEKF_TUNE_TILES         the tile family of the fused step (P as fp64-MFMA accumulator tiles): 0 = never, 1 = automatic (its
- *                            paired form once the batch exceeds one filter per CU), 2 = its one-filter-per-workgroup form,
- *                            3 = its paired form (two filters per workgroup) -- 2 and 3 whatever the batch size */
+ *   VIEKF_TUNE_TILES         the tile family of the fused step (P as fp64-MFMA accumulator tiles, N = 46..50): 0 / 1 = not used
+ *                            (the default: the resident family measures faster on the MI355X at every batch size), 2 = its
+ *                            one-filter-per-workgroup form, 3 = its paired form (two filters per workgroup) */
 typedef enum viekf_tuning {
   VIEKF_TUNE_RES_INSTANCE = 1, VIEKF_TUNE_UNIT_LAMBDA = 2, VIEKF_TUNE_BLOCK_GROUP = 3, VIEKF_TUNE_STREAM_MFMA = 4, VIEKF_TUNE_TILES = 5
 } viekf_tuning;

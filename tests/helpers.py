@@ -56,11 +56,11 @@ def make_twin(N, params, pix=None, depth=None):
 
 
 def apply_kernel(g, kernel):
-    """kernel selection shared by the GPU tests: 0 automatic, 1 streaming family, 2 on-chip families, 3 the tile family whatever the
-    batch size (automatic only beyond one workgroup per CU), 4 on-chip without the tile family"""
+    """kernel selection shared by the GPU tests: 0 automatic, 1 streaming family, 2 on-chip families, 3 and 5 the tile family (single, paired;
+    opt-in), 4 on-chip without the tile family"""
     from vi_ekf_amd import capi
-    if kernel in (3, 5):        # 3: one filter per workgroup, 5: the paired form (two filters per workgroup, the automatic choice for
-        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)        # batches beyond one filter per CU)
+    if kernel in (3, 5):        # 3: one filter per workgroup, 5: the paired form (two filters per workgroup); both opt-in, the
+        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)        # resident family is the default
         assert ("k_step_tiles_pair" if kernel == 5 else "k_step_tiles<") in g.describe(), g.describe()
     elif kernel == 4:
         g.set_tuning(capi.TUNE_TILES, 0)

@@ -60,8 +60,8 @@ def make_gpu(sc, B, N, nfeat=None, kernel=0):
     batch size -- it is otherwise chosen only for batches beyond one workgroup per CU --, 4 on-chip without the tile family"""
     from vi_ekf_amd import capi
     g = v.BatchVIEKF(B, N, sc["params"])
-    if kernel in (3, 5):        # 3: one filter per workgroup, 5: the paired form (two filters per workgroup, the automatic choice for
-        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)        # batches beyond one filter per CU)
+    if kernel in (3, 5):        # 3: one filter per workgroup, 5: the paired form (two filters per workgroup); both opt-in, the
+        g.set_tuning(capi.TUNE_TILES, 2 if kernel == 3 else 3)        # resident family is the default
         assert ("k_step_tiles_pair" if kernel == 5 else "k_step_tiles<") in g.describe(), g.describe()
     elif kernel == 4:
         g.set_tuning(capi.TUNE_TILES, 0)

@@ -93,7 +93,7 @@ struct viekf_batch {
   size_t pin_bytes = 0, pin_used = 0;
   int tile_inst = -1;          // tile family (P as MFMA accumulator tiles): index into kTileInst, -1 = not used for this batch
   size_t tile_lds = 0;
-  int tune_tiles = 1;          // 0: never the tile family
+  int tune_tiles = 0;          // the tile family is opt-in (measured slower than the resident family): 2 single, 3 pair
   int tune_res_inst = -1;      // >= 0: only this index of kResInst is tried
   int tune_unit_lambda = 1;    // 0: never the unit-Lambda instances
   int tune_block_group = 0;    // 16 / 24 / 32: group size of the grouped update where its panel fits
@@ -523,9 +523,9 @@ int setup_tiles(viekf_batch* b) {
   for (int i = 0; i < (int)(sizeof(kTileInst) / sizeof(kTileInst[0])); i++) {
     const TileInst& r = kTileInst[i];
     if (r.NT != NT || 16 * NT > 64 * r.NW) continue;   // (one worker thread per tile-space row brings the next column pair up to date)
-    // tune_tiles: 1 automatic (pairs once the batch exceeds one filter per CU, nothing below that: the resident family's
-    // one-workgroup-per-CU instances run small batches), 2 the single form, 3 the paired form -- whatever the batch size
-    if (b->tune_tiles == 1 && !(r.pair && b->B > cus)) continue;
+    // tune_tiles: 0 / 1 the resident family (on the MI355X it is the faster one at every batch size measured, so "automatic"
+    // never picks a tile instance), 2 the single form, 3 the paired form -- whatever the batch size
+    if (b->tune_tiles == 1) continue;
     if (b->tune_tiles == 2 && r.pair) continue;
     if (b->tune_tiles == 3 && !r.pair) continue;
     const TileLds L(b->N, b->n, b->nxs);

@@ -1452,9 +1452,9 @@ __global__ __launch_bounds__(T) void k_keep_features(StreamArgs a, const unsigne
     int w = 0;
     for (int f = 0; f < len; f++)
       if (keep[f]) { if (w != f) for (int q = 0; q < 5; q++) xg[xZ + 5 * w + q] = xg[xZ + 5 * f + q]; w++; }
-    for (int i = xZ + 5 * k; i < xZ + 5 * len; i++) xg[i] = 0.0;
-  }
-  const int nk = 16 + 3 * k, nold = 16 + 3 * len;
+    for (int i = xZ + 5 * k; i < xZ + 5 * N; i++) xg[i] = 0.0;   // "clean up the rest" (vi_ekf_feat.cpp:66-69): EVERYTHING past the
+  }                                                              // kept features, also what a replay from older history left there
+  const int nk = 16 + 3 * k, nold = n;
   for (int jn = 0; jn < nold; jn++) {
     const int jo = (jn < nk) ? srcrow[jn] : -1;
     if (jo >= 0) for (int i = tid; i < nk; i += T) colbuf[i] = P[srcrow[i] + (long)jo * ld];

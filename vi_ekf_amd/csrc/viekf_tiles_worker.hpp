@@ -331,10 +331,9 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   __syncthreads();  // B1 : the service published the first measurement's G and verdict
   RES_STAMP(S, st0, 73);
   int cnt = 0;
-  // mu = 1 - lambda of this lane's row inside a feature tile / the body tile, folded into the operand factors
+  // (mu = 1 - lambda of this lane's rows is read from the LDS copy of lambda inside every phase: held in registers across the
+  //  loop, those six registers were what pushed an accumulator tile of the third worker wave into scratch)
   const bool partial = prm.use_partial_update != 0;
-  const double muF = tile_mu(S.lam, 16 + l15, nf, partial), muB = tile_mu(S.lam, l15, nf, partial);
-  const double mq_own = tile_mu(S.lam, min(tid, NQ - 1), nf, partial);                         // of the row this thread brings up to date
   const double mz0 = uniform_f64(tile_mu(S.lam, 16, nf, partial)), mz1 = uniform_f64(tile_mu(S.lam, 17, nf, partial));   // lambda_feat is the same for every slot
   // ONE barrier per update.  Inside a phase the worker waves (1) form their operands from the current column pair C_m and the
   // 2x2 G_m = Hb^T S^-1 Hb of the service wave and issue one MFMA per tile:  P -= Lambda o (C G C^T)  (= the reference's
@@ -364,35 +363,49 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
     const int fq = min(tid, NQ - 1), qs = tile_qrow(max(snext, 0), 0);
     const double* En = S.Eb + ((cnt + 1) & 1) * 2 * NQ;
     if (run) {
+      const int ln_ = opaque(lane), l15 = ln_ & 15, lg = ln_ >> 4;
       const bool odd = (lg & 1) != 0;
+      const double muF = tile_mu(S.lam, 16 + l15, nf, partial), muB = tile_mu(S.lam, l15, nf, partial);
       const double fAF = (lg < 2) ? 1.0 : muF, fAB = (lg < 2) ? 1.0 : muB;        // TJ side:  C[k & 1] x {1, 1, mu, mu}
       const double fBF = (lg < 2) ? -1.0 : muF, fBB = (lg < 2) ? -1.0 : muB;      // TI side: Kg[k & 1] x {-1, -1, mu, mu}
       const double ga = odd ? g01 : g00, gb = odd ? g11 : g01;                  // column k & 1 of G
       const double gaF = ga * fBF, gbF = gb * fBF, gaB = ga * fBB, gbB = gb * fBB;
       const double* Cl = Cc + 2 * l15;
-      double aop[NT];
-      double2 craw[NT];
+      const double* Ck = Cl + (lg & 1);
+      // slot by slot (a wave's slots are ordered by TI): the A-side value of slot s + 2 and, at a row's first slot, the column-pair
+      // rows of the row after next are read ahead -- a matrix instruction's operands are then in registers when its turn comes,
+      // and only three of each are alive at a time (an array of all eleven A-side operands was spilled inside this loop)
+      double ar[CNT + 2];
+      double2 craw[NT + 2];
       double2 fe = {0.0, 0.0}, fc = fe;
-      craw[0] = lds_ld2(Cl);
-      if (NT > 1) craw[1] = lds_ld2(Cl + 32);
-      constexpr int FL = NT > 6 ? 3 : 0, FC = NT > 6 ? 6 : NT - 1;   // rows after which the next pair's inputs are read / it is formed
-      static_for<NT>([&](auto tc) {
-        constexpr int TR = decltype(tc)::value;
-        if (TR + 2 < NT) craw[TR + 2 < NT ? TR + 2 : 0] = lds_ld2(Cl + 32 * (TR + 2));
-        const double2 c = craw[TR];
-        aop[TR] = (odd ? c.y : c.x) * ((TR == 0) ? fAB : fAF);
-        const double bop = (TR == 0) ? fma(c.y, gbB, c.x * gaB) : fma(c.y, gbF, c.x * gaF);
-        static_for<CNT>([&](auto sc) {
-          constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
-          if (TI == TR) X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[TJ], bop, X[s], 0, 0, 0);
-        });
+      double bop = 0.0;
+      constexpr int FC = CNT > 8 ? CNT / 2 : CNT - 1, FL = FC > 2 ? FC - 2 : 0;   // slots after which the next pair's inputs are read / it is formed
+      static_for<2>([&](auto pc) {
+        constexpr int s0 = decltype(pc)::value;
+        if (s0 < CNT) ar[s0] = Ck[32 * Map::tj(W, s0 < CNT ? s0 : 0)];
+      });
+      // (rows this wave holds tiles of, in order: row r of them is Map::ti of the first slot of the r-th run)
+      static_for<CNT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
+        constexpr int prevTI = (s == 0) ? -1 : Map::ti(W, s == 0 ? 0 : s - 1);
+        constexpr bool newrow = TI != prevTI;
+        if (s + 2 < CNT) ar[s + 2 < CNT ? s + 2 : 0] = Ck[32 * Map::tj(W, s + 2 < CNT ? s + 2 : 0)];
+        if (newrow) {
+          // this row's pair was requested one row-start earlier (or here, for the wave's first row); request the next row's
+          constexpr int nextTI = [] { for (int q = s + 1; q < CNT; q++) if (Map::ti(W, q) != TI) return Map::ti(W, q); return -1; }();
+          if (s == 0) craw[TI] = lds_ld2(Cl + 32 * TI);
+          if (nextTI >= 0) craw[nextTI >= 0 ? nextTI : 0] = lds_ld2(Cl + 32 * (nextTI >= 0 ? nextTI : 0));
+          const double2 c = craw[TI];
+          bop = (TI == 0) ? fma(c.y, gbB, c.x * gaB) : fma(c.y, gbF, c.x * gaF);
+        }
+        const double aop = ar[s] * ((TJ == 0) ? fAB : fAF);
+        X[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, X[s], 0, 0, 0);
         // next measurement's column pair:  C_{m+1}[q] = E[q] - Lambda(q, zeta_c) (C G C^T)[q][zeta_c], one row per thread
-        if (TR == FL && snext >= 0) { fe = lds_ld2(En + 2 * fq); fc = lds_ld2(Cc + 2 * fq); }
-        if (TR == FC && snext >= 0) {
+        if (s == FL && snext >= 0) { fe = lds_ld2(En + 2 * fq); fc = lds_ld2(Cc + 2 * fq); }
+        if (s == FC && snext >= 0) {
           const double2 fcs0 = lds_ld2(Cc + 2 * qs), fcs1 = lds_ld2(Cc + 2 * qs + 2), fes = lds_ld2(En + 2 * qs);
           const double kg0 = fma(fc.y, g01, fc.x * g00), kg1 = fma(fc.y, g11, fc.x * g01);
-          double mq = mq_own;
-          asm volatile("" : "+v"(mq));   // (Lambda's factors are formed here, not hoisted and held across the loop)
+          const double mq = tile_mu(S.lam, opaque(fq), nf, partial);   // (read here: not held across the loop)
           fe.x = fma(-fma(-mq, mz0, 1.0), fma(kg1, fcs0.y, kg0 * fcs0.x), fe.x);
           fe.y = fma(-fma(-mq, mz1, 1.0), fma(kg1, fcs1.y, kg0 * fcs1.x), fe.y);
           // the feature's own 2x2 stays exactly symmetric: element (zeta1, zeta0) takes the value row zeta0 forms for (zeta0, zeta1)
