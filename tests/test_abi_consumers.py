@@ -246,6 +246,9 @@ def test_reference_call_sites_flight_matches_restated_plumbing(tmp_path, last_k)
             bg, ba = rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)
             rec(8, t, *bg, *ba)
             o.set_imu_bias(bg, ba)
+        if k == 12:
+            rec(4, t, 6, *ids_all)                           # every feature still seen: the first call records the keyframe's features
+            o.keep_only_features(ids_all)                    # (vi_ekf_feat.cpp:131-139), nothing is removed, no reset
         if k == 30:
             rec(4, t, 3, 0, 2, 5)                            # 3 of 6 < 0.8: features 1, 3, 4 dropped, keyframe reset
             o.keep_only_features([0, 2, 5])

@@ -124,7 +124,7 @@ def test_general_lambda_instances_full_batch(N):
     assert " ZU" not in g.describe()
 
 
-@pytest.mark.parametrize("N,group", [(85, 0), (85, 16), (85, 24), (100, 0), (100, 16), (120, 24)])
+@pytest.mark.parametrize("N,group", [(85, 0), (85, 16), (85, 24), (100, 0), (100, 16), (90, 24)])
 def test_wide_p_group_sizes(N, group):
     """the grouped update's 24- and 32-measurement instances (chosen on their own for n > 256 where the panel fits: N = 85 ->
     32, N = 100 -> 24) and forced group sizes, more measurements than one group: x, P (whole, mirrored from the lower

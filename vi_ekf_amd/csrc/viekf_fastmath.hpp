@@ -4,6 +4,16 @@
 #pragma once
 #include "viekf_device.hpp"
 
+// Accounting build only (-DVIEKF_ISA_MARKS, tools/isa_regions.py): brackets around code a usual update never executes, so the
+// listing's per-region counts can be split into the executed path and the rest.
+#ifdef VIEKF_ISA_MARKS
+#define VIEKF_COLD_BEGIN() do { __builtin_amdgcn_sched_barrier(0); asm volatile("; @@COLD begin"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VIEKF_COLD_END() do { __builtin_amdgcn_sched_barrier(0); asm volatile("; @@COLD end"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VIEKF_COLD_BEGIN() do {} while (0)
+#define VIEKF_COLD_END() do {} while (0)
+#endif
+
 namespace viekf {
 
 // 1/d from v_rcp_f64 and two Newton steps (5 instructions; the IEEE division expands to ~14 with a longer dependent chain)
@@ -45,6 +55,7 @@ __device__ __forceinline__ void q_exp_fast(const double* v, double* o) {
     s *= 0.5;
     o[0] = c; o[1] = s * v[0]; o[2] = s * v[1]; o[3] = s * v[2];
   } else if (h2 < 0.0625) {
+    VIEKF_COLD_BEGIN();
     double c = kconst(-1.0 / 20922789888000.0);          // -1/16!
     c = fma(c, h2, kconst(1.0 / 87178291200.0));          // 1/14!
     c = fma(c, h2, kconst(-1.0 / 479001600.0));           // -1/12!
@@ -64,8 +75,11 @@ __device__ __forceinline__ void q_exp_fast(const double* v, double* o) {
     s = fma(s, h2, 1.0);                          // sin(h)/h
     s *= 0.5;
     o[0] = c; o[1] = s * v[0]; o[2] = s * v[1]; o[3] = s * v[2];
+    VIEKF_COLD_END();
   } else {
+    VIEKF_COLD_BEGIN();
     q_exp(v, o);
+    VIEKF_COLD_END();
   }
 }
 

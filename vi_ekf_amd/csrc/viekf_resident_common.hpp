@@ -116,6 +116,19 @@ __device__ __forceinline__ double uniform_f64(double v) {   // force a wave-unif
 #define RES_STAMP(S_, who, idx) do {} while (0)
 #endif
 
+// Accounting build only (-DVIEKF_ISA_MARKS, tools/isa_regions.py): named marks in the ISA listing, fenced so that nothing is
+// scheduled across them -- the per-region instruction counts of profiles/r03/isa_step_resident_7_3.json.
+#ifdef VIEKF_ISA_MARKS
+#define RES_MARK(name)                          \
+  do {                                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    asm volatile("; @@MARK " name);             \
+    __builtin_amdgcn_sched_barrier(0);          \
+  } while (0)
+#else
+#define RES_MARK(name) do {} while (0)
+#endif
+
 // Timing-only ablation bits (results become wrong) exist in a -DVIEKF_ABLATE diagnostic build only; the product build has none.
 #ifdef VIEKF_ABLATE
 #define RES_ABLATE(S_, bit) (((S_).dbg & (bit)) != 0)

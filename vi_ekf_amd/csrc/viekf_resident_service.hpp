@@ -294,6 +294,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   int it_ = 0, cnt = 0;
 
   while (m < M) {
+    RES_MARK("service.next_rows");
     const int mnext = sq.x, slot_next = sq.y;
     // this lane's rows of the gain (formed by this wave at the end of the previous phase); rows 0,1 also feed its own P_zz
     const double* kP = (cnt & 1) ? S.Z : S.Kt;   // (double-buffered, see the worker side)
@@ -306,6 +307,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     double2 prn[3] = {};
     if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !RES_ABLATE(S, 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
     RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
+    RES_MARK("service.correction");
     // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
     const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
     const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
@@ -341,6 +343,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
+    RES_MARK("service.fix_depth");
     // (fix_depth mailbox flag: one word per service wave -- [40 + par] / [36 + par] -- each wave clears and sets its own)
     constexpr int FIXW = (ROLE == 2) ? 36 : 40;
     if (lane == 0) sm[FIXW + par] = 0.0;
@@ -348,6 +351,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const bool odd_depth = !gated && isfeat && fid < len && !(lin >= 0.0 && lin <= 1e2);
     if (__any(odd_depth)) {
       if (odd_depth) {
+        VIEKF_COLD_BEGIN();
         double rho = lin;
         if (rho != rho) { rho = rho_reset; flag |= FLAG_NAN; }
         if (rho < 0.0) {
@@ -362,9 +366,11 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
           rho = rho_reset;
         }
         lin = rho;
+        VIEKF_COLD_END();
       }
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 2);
+    RES_MARK("service.predict");
     if (slot_next >= 0) {   // next measurement, from registers, on the wave that holds its feature
       const int sn = __builtin_amdgcn_readfirstlane(slot_next);
       if (holds(sn)) { predict(f1, f2, fz, mnext, lane_of(sn), nxt); if (ROLE != 0) send(nxt, (cnt + 1) & 1, cnt + 2); }
@@ -372,7 +378,9 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     }
     if (PRIMARY && result_all && lane == 0) result_all[(long)S.b * S.mstride + m] = gated ? 1 : 0;
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 3);
+    RES_MARK("service.gain_rows");
     if (slot_next >= 0) gain_rows(nxt, 44 + (cnt + 1) % 3, 50 + ((cnt + 1) & 1), prn, (cnt & 1) ? S.Kt : S.Z, nrow);
+    RES_MARK("service.phase_tail");
     cur = nxt;
     crow = nrow;
     par ^= 1;
@@ -383,6 +391,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     it_++;
     m = mnext;
   }
+  RES_MARK("service.loop_end");
 
   if (hasq) { qptr[0] = qn[0]; qptr[1] = qn[1]; qptr[2] = qn[2]; qptr[3] = qn[3]; }
   if (haslin) *linptr = lin;

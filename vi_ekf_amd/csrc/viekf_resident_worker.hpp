@@ -300,10 +300,12 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   auto apply_fixes = [&](int mb, double pending) {
     if (pending == 0.0) return;   // nothing posted (the common case); the flag word was read ahead of the barrier
     if (own_diag && tid_ < len) {
+      VIEKF_COLD_BEGIN();
       const int I = tid_;
       const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
       if (ad != 0.0) { pb[0][8] += ad; S.fixadd[mb * N + I] = 0.0; }
       if (st != 0.0) { pb[0][8] = p0rr; S.fixset[mb * N + I] = 0.0; }
+      VIEKF_COLD_END();
     }
   };
   // Publishes the feature rows of the two zeta columns of feature `slot` (raw P[16.., j0], P[16.., j0+1]) into Praw for the
@@ -373,6 +375,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const int mnext = sq.x;
     // gain rows {K [n][2], W [n][2]} are double-buffered: the service wave forms those of measurement m+1 while step (3) of
     // this phase still reads those of measurement m.  The second buffer is the Z region (free outside the propagate).
+    RES_MARK("worker.phase_top");
     const double* kP = (cnt & 1) ? S.Z : S.Kt;
     const double* wP = kP + 2 * n;
     __builtin_amdgcn_s_setprio(1);
@@ -386,6 +389,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     // ---- (1) feature/feature blocks (registers).  The operand rows of GB blocks are in flight together: all of them with
     //      few blocks per thread; two at a time with many, where holding every block's rows would not fit the register file
     constexpr int GB = (RB <= 4) ? RB : 2;
+    RES_MARK("worker.block_sweep");
     const bool gated = gflag != 0.0;
     const bool run = !gated && nanw == 0.0 && !RES_ABLATE(S, 1);   // not gated, no NaN guard
     bool fixed = false;
@@ -422,6 +426,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       group_fence<(RB > GB)>();
     }
     sym_diag();
+    RES_MARK("worker.column_extraction");
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 0);
     // ---- (2) the raw feature rows of the measurement after next (a fix_depth edit touches P(rho,rho) only, never these
     //      columns), into the buffer the service wave is not reading in this phase
@@ -431,10 +436,12 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
     __builtin_amdgcn_sched_barrier(0);
+    RES_MARK("worker.body_items");
     // ---- (3) body columns, in LDS (res_body_items).  Wave 0 takes the last places in the item order, so that the incomplete
     //      final round falls to the other waves: it is the longest of the workers whenever its SIMD-mate is the other workgroup's
     //      service wave.
     res_body_items(S, kP, run, (it >= 64) ? it - 64 : it + TW - 64, TW, 0, 8 * N, sq.y, rawdst);
+    RES_MARK("worker.body_block");
     if (run) {   // body block: 2 adjacent elements per task, 128 tasks on the top 128 threads (a single worker wave: two tasks
                  // per thread).  Element (r, c) and its mirror (c, r) are owned by different tasks; both form
                  // p - L (K_lo . W_hi), lo = min(r, c), hi = max(r, c)  from their own (equal) copies, so the block stays exactly
@@ -458,6 +465,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
         *reinterpret_cast<double2*>(Pbb + br * 16 + bc2) = bpv;
       }
     }
+    RES_MARK("worker.phase_tail");
     par ^= 1;
     cnt++;
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 2);
@@ -468,6 +476,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     it_++;
     m = mnext;
   }
+  RES_MARK("worker.loop_end");
   apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
   RES_STAMP(S, tid == 0, 72);
   __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
