@@ -71,8 +71,8 @@ struct viekf_batch {
   DevParams* d_dp = nullptr;
   // P is symmetric and the hot kernels keep only its LOWER triangle current; what is above the diagonal may be stale:
   //   0  all of P valid
-  //   1  stale outside the diagonal 48 x 48 super-tiles (left by the grouped update; the matrix-core propagate copes)
-  //   2  stale everywhere above the diagonal 3 x 3 blocks (left by the fused kernel, which stores the lower triangle only)
+  //   2  stale above the diagonal (left by the fused kernels, the matrix-core propagate and the grouped update: all of them read
+  //      and write the lower triangle only)
   // ensure_full_P mirrors the lower triangle up before anything that reads all of P.
   int upper_stale = 0;
   int stale_ever = 0;         // the highest level any launch of this batch has left: a ring slot is taken to be that stale when
@@ -202,13 +202,13 @@ int ensure_full_P(viekf_batch* b, int tolerate = 0) {
 bool stream_mfma_ok(const viekf_batch* b) { return b->tune_stream_mfma != 0; }
 
 int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
-  if (int rc = ensure_full_P(b, stream_mfma_ok(b) ? 1 : 0)) return rc;
+  if (int rc = ensure_full_P(b, stream_mfma_ok(b) ? 2 : 0)) return rc;
   StreamArgs a = make_args(b);
-  if (stream_mfma_ok(b)) {   // feature/feature part on the fp64 matrix cores: reads the lower triangle, writes all of P
-    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2 + 8 * 16 * 17),
+  if (stream_mfma_ok(b)) {   // feature/feature part on the fp64 matrix cores: reads and writes the lower triangle only
+    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2),
                        b->stream, a, d_u, d_dt);
-    // ... of the filters that take part: under a participation mask the others keep whatever staleness they had
-    if (!b->active_on) b->upper_stale = 0;
+    b->upper_stale = 2;
+    b->stale_ever = 2;
   } else
     hipLaunchKernelGGL((k_propagate_stream<kThreads, false>), dim3(b->B), dim3(kThreads), lds_propagate(b), b->stream, a, d_u,
                        d_dt);
@@ -238,7 +238,6 @@ int blocked_group(const viekf_batch* b, size_t* lds_bytes) {
 
 int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, const double* d_R, int r_mode,
                   int* d_res) {
-  if (int rc = ensure_full_P(b)) return rc;   // (the panel loads read whole columns)
   StreamArgs a = make_args(b);
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
@@ -246,7 +245,7 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   // wide P, several measurements: the blocked kernel (one HBM pass over P per group of BG measurements, fp64 MFMA pass)
   size_t blds = 0;
   const int bg = blocked_group(b, &blds);
-  if (M >= 2 && bg > 0) {
+  if (M >= 1 && bg > 0) {   // (a single measurement too: a group of one, no mirror pass before it)
     typedef void (*blk_kernel_t)(StreamArgs, const double*, const int*, int, const double*, long, long, int*);
     const blk_kernel_t kern = bg == 32 ? k_update_feat_blocked<512, 32> : (bg == 24 ? k_update_feat_blocked<512, 24> : k_update_feat_blocked<512, 16>);
     {
@@ -259,9 +258,10 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
       }
     }
     hipLaunchKernelGGL(kern, dim3(b->B), dim3(512), blds, b->stream, a, d_z, d_slot, M, d_R, rsb, rsm, d_res);
-    b->upper_stale = 1;
-    if (b->stale_ever < 1) b->stale_ever = 1;
+    b->upper_stale = 2;   // (reads and writes the lower triangle only)
+    b->stale_ever = 2;
   } else {
+    if (int rc = ensure_full_P(b)) return rc;   // (the one-measurement kernel reads whole columns)
     hipLaunchKernelGGL(k_update_feat_stream<kThreads>, dim3(b->B), dim3(kThreads), lds_update(b), b->stream, a, d_z,
                        d_slot, M, d_R, rsb, rsm, d_res);
   }
@@ -849,7 +849,7 @@ int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
     const int bg = blocked_group(b, nullptr);
     if (bg > 0)
       snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_blocked<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
-               "passes; a single measurement: k_update_feat_stream)", bg, bg);
+               "passes, lower triangle only)", bg, bg);
     else
       snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_stream (P in HBM/L2, one pass per measurement)");
   }

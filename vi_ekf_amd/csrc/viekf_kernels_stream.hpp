@@ -105,7 +105,6 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   double* xdb = T16 + 256;              // 16
   BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
   double* Dl = xdb + 16 + (sizeof(BodyCtx) + 7) / 8;   // [N][9] Phi_ff blocks (MF only)
-  double* Tr = Dl + 9 * a.N + (a.N & 1);              // [T / 64][16 x 17] transpose tiles (MF only)
 
   double* xg = a.x + (long)b * a.nxs;
   double* P = a.P + (long)b * n * ld;
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
     double g = 0.0;
     for (int q = 0; q < 6; q++) g += gd[(16 + r) * 6 + q] * a.dp->Qu[q] * Gdb[k * 6 + q];
     P[(16 + r) + (long)k * ld] = s + g;
-    P[k + (long)(16 + r) * ld] = s + g;
+    if (!MF) P[k + (long)(16 + r) * ld] = s + g;   // (the matrix-core variant keeps the lower triangle only, see below)
   }
   if constexpr (MF) {
     // ---- feature/feature part on the matrix cores.  With D = blockdiag(Phi_ff) the new block is
@@ -301,8 +300,10 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
       const int fp = jp / 3, f = j / 3, F = 16 * sup + fp;
       return (fp == f && F < len) ? Dl[9 * F + (jp - 3 * fp) * 3 + (j - 3 * f)] : 0.0;
     };
-    // Only the super-tiles on and below the diagonal are computed (elements i >= j stored); the upper triangle is filled by
-    // the transpose pass that follows -- P+ is symmetric bit for bit, and P_ff is read once, not twice.
+    // Only the super-tiles on and below the diagonal are computed and only the elements i >= j stored: the hot kernels (this one,
+    // the grouped update, the fused step) read the LOWER triangle of P only, so nothing above the diagonal is written here --
+    // r02's transpose pass cost one more read and one more write of half the matrix per step.  The host marks the batch
+    // (upper_stale) and mirrors the triangle up (k_mirror_upper) before anything reads P whole.
     for (int st = wave; st < nst * nst; st += NWV) {
       const int I = st % nst, J = st / nst;
       if (I < J) continue;
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
       for (int aa = 0; aa < 3; aa++)
 #pragma unroll
         for (int s = 0; s < 12; s++)
-          pA[aa][s] = P[min(r0 + 16 * aa + lr, nact - 1) + (long)min(c0 + 4 * s + lk, nact - 1) * ld];
+        {   // (a diagonal super-tile: the elements above the diagonal through their mirrors -- only the lower triangle is valid)
+          const int pi = min(r0 + 16 * aa + lr, nact - 1), pj = min(c0 + 4 * s + lk, nact - 1);
+          pA[aa][s] = P[max(pi, pj) + (long)min(pi, pj) * ld];
+        }
       v4f64 R[3][3], O[3][3];
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -369,30 +373,6 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
             }
           }
         }
-    }
-    __syncthreads();   // (this block's stores are visible to it after the barrier)
-    // transpose pass: upper triangle of the feature part <- lower triangle, 16 x 16 tiles through a padded LDS tile per wave
-    // (coalesced on both sides: lanes along the rows of the source tile, then along the rows of the destination tile)
-    {
-      double* tt = Tr + wave * (16 * 17);
-      const int ntf = (nf + 15) >> 4;
-      for (int t = wave; t < ntf * ntf; t += NWV) {
-        const int ti = t % ntf, tj = t / ntf;
-        if (ti < tj) continue;
-        const int i0 = 16 + 16 * ti, j0 = 16 + 16 * tj;
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int i = min(i0 + lr, nact - 1), j = min(j0 + lk + 4 * rg, nact - 1);
-          tt[(lk + 4 * rg) * 17 + lr] = P[i + (long)j * ld];          // tt[c][r] = P[i0 + r][j0 + c]
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const int jj = j0 + lr, ii = i0 + lk + 4 * rg;               // destination element (row jj, column ii), jj < ii
-          if (jj < ii && ii < nact && jj < nact) P[jj + (long)ii * ld] = tt[lr * 17 + lk + 4 * rg];
-        }
-        wave_lds_fence();
-      }
     }
   } else {
     // ---- feature/feature 3x3 blocks, in place (each block needs only itself + saved body strips)
@@ -630,10 +610,10 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   double* Wp = smem + L.Wp;     // panel of raw columns, turned into W pair by pair
   double* SiL = smem + L.Si;    // per pair g: {Si00, Si10, Si01, Si11} = the two COLUMNS of S^-1 (zero if the update was skipped)
   double* pzz = smem + L.sm;    // [2][4] zeta-zeta block of the current / next measurement
+  int* badf = reinterpret_cast<int*>(pzz + 8);   // [BG] NaN-guard verdict of each measurement of the group (set by any thread)
   double* diag = smem + L.diag; // running P(rho_f, rho_f)
   int* gsl = reinterpret_cast<int*>(smem + L.gsl);
   int* gml = gsl + BG;
-  __shared__ unsigned needw;    // 16-column blocks that hold a zeta column of a measurement still to come in this launch
   double* wz = smem + L.win;
   double* wR = wz + 2 * BWIN;
   int* wsl = reinterpret_cast<int*>(wR + 4 * BWIN);
@@ -693,24 +673,12 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       mbase = m0;
     }
     if (Gn == 0) continue;
-    // Which mirror tiles does the pass of this group have to write?  P is symmetric and only its lower triangle is read by the
-    // pass; the part above the diagonal is read (a) by the panel loads of LATER groups -- whole zeta columns -- and (b) by the
-    // matrix-core propagate inside its diagonal 48 x 48 super-tiles.  Everything else above the diagonal is left STALE (the
-    // host marks the batch and mirrors the lower triangle up before anything else reads P): mirrored full-P stores in every
-    // pass were half of this kernel's HBM writes.
-    if (tid == 0) needw = 0u;
-    __syncthreads();
-    {
-      unsigned mine = 0u;
-      for (int e = m + tid; e < M; e += T) {
-        const int sl = slot_all[(long)b * M + e];
-        if (sl >= 0 && sl < len) { const int c = 16 + 3 * sl; mine |= (1u << (c >> 4)) | (1u << ((c + 1) >> 4)); }
-      }
-      if (mine) atomicOr(&needw, mine);
-    }
-    __syncthreads();
-    const unsigned need = needw;
-    // ---- 1. panel <- the zeta columns of the group's features (coalesced along the rows); unused columns <- 0
+    // ---- 1. panel <- the zeta columns of the group's features; unused columns <- 0.  Only the LOWER triangle of P is valid:
+    //      element (i, c) of a column comes from the column where i >= c (coalesced along the rows) and from ROW c where i < c
+    //      (one 8-byte read per thread, a column apart; the rows of a group's features are mostly neighbours -- measurements
+    //      arrive in slot order -- so a thread's reads share 128-byte lines).  That costs about a quarter of a pass in fetched
+    //      lines per group and saves the mirrored stores of every pass (r02: up to the whole upper triangle per pass, the
+    //      kernel's largest single write stream) and the propagate's transpose pass.
     for (int i = tid; i < nact; i += T) {
 #pragma unroll 1
       for (int c0 = 0; c0 < 2 * BG; c0 += 8) {           // eight independent column loads in flight per thread
@@ -718,17 +686,22 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           const int c = c0 + k;
-          v[k] = (c < 2 * Gn) ? P[i + (long)(16 + 3 * gsl[c >> 1] + (c & 1)) * ld] : 0.0;
+          const int col = 16 + 3 * gsl[(c < 2 * Gn) ? (c >> 1) : 0] + (c & 1);
+          v[k] = (c < 2 * Gn) ? P[max(i, col) + (long)min(i, col) * ld] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(Wp + i * BLD + c0 + k) = make_double2(v[k], v[k + 1]);
       }
     }
     if (tid < 4 * BG) SiL[tid] = 0.0;
+    if (tid < BG) badf[tid] = 0;
     for (int f = tid; f < len; f += T) diag[f] = P[(16 + 3 * f + 2) + (long)(16 + 3 * f + 2) * ld];
     // The zeta-zeta 2x2 of the measurement about to be processed is handed over in pzz[parity][4] by the two threads that own
     // its rows (they are the ones that keep those panel entries current), so nobody reads panel rows that are being rewritten.
     const int i = tid;                                      // this thread's row of the panel (T >= n, checked on the host)
+    // Lambda of (this row, a bearing column):  lambda_i + lambda_c - lambda_i lambda_c  with the bearing components' lambda_c
+    double Lza = 1.0, Lzb = 1.0;
+    if (partial) { const double li = lam[min(i, n - 1)], la = lam[16], lb = lam[17]; Lza = la + li - li * la; Lzb = lb + li - li * lb; }
     auto publish_pzz = [&](int gn) {                        // for measurement gn of the group, from the thread's own row
       if (gn < Gn) {
         const int jn = 16 + 3 * gsl[gn];
@@ -800,7 +773,9 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
         if (k0 != k0 || k1 != k1) bad = 1;
       }
       if (h00 != h00 || h01 != h01 || h10 != h10 || h11 != h11) bad = 1;
-      bad = __syncthreads_or(bad);                         // barrier 1: the W pair is complete
+      if (bad) badf[g] = 1;                                // (a flag word and ONE barrier: __syncthreads_or is a workgroup reduction,
+      __syncthreads();                                     //  two barriers and an LDS round trip per measurement)
+      bad = badf[g];                                       // barrier 1: the W pair is complete
       if (bad) {
         if (i < nact) *reinterpret_cast<double2*>(Wp + i * BLD + 2 * g) = make_double2(0.0, 0.0);
       } else {
@@ -847,17 +822,29 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
           diag[f] -= Lii * (k2[0] * wr.x + k2[1] * wr.y);
         }
         // the later panel columns follow the update:  P_ic -= Lambda_ic (K_i . W_c), this thread's row
+        // Four column pairs per trip, their operands loaded together: one pair at a time is a chain of LDS round trips (the
+        // compiler keeps every load behind the previous pair's store), about a quarter of the measurement's latency at 16 per group.
+        // (The mask of a (row, bearing column) pair is the same for every feature: lambda_feat is one triple for all slots.)
         if (i < nact) {
-          const double li = lam[i];
-          for (int gc = g + 1; gc < Gn; gc++) {
-            const int cr = 16 + 3 * gsl[gc];
-            const double2 wa = *reinterpret_cast<const double2*>(Wp + cr * BLD + 2 * g);
-            const double2 wb = *reinterpret_cast<const double2*>(Wp + (cr + 1) * BLD + 2 * g);
-            const double la = lam[cr], lb = lam[cr + 1];
-            double2 pc = *reinterpret_cast<double2*>(Wp + i * BLD + 2 * gc);
-            pc.x -= (partial ? (la + li - li * la) : 1.0) * (k0 * wa.x + k1 * wa.y);
-            pc.y -= (partial ? (lb + li - li * lb) : 1.0) * (k0 * wb.x + k1 * wb.y);
-            *reinterpret_cast<double2*>(Wp + i * BLD + 2 * gc) = pc;
+#pragma unroll 1
+          for (int gc0 = g + 1; gc0 < Gn; gc0 += 4) {
+            double2 wa[4], wb[4], pc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int gc = min(gc0 + q, Gn - 1);
+              const int cr = 16 + 3 * gsl[gc];
+              wa[q] = *reinterpret_cast<const double2*>(Wp + cr * BLD + 2 * g);
+              wb[q] = *reinterpret_cast<const double2*>(Wp + (cr + 1) * BLD + 2 * g);
+              pc[q] = *reinterpret_cast<const double2*>(Wp + i * BLD + 2 * gc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (gc0 + q < Gn) {
+                pc[q].x -= Lza * (k0 * wa[q].x + k1 * wa[q].y);
+                pc[q].y -= Lzb * (k0 * wb[q].x + k1 * wb[q].y);
+                *reinterpret_cast<double2*>(Wp + i * BLD + 2 * (gc0 + q)) = pc[q];
+              }
+            }
           }
         }
       }
@@ -874,9 +861,8 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
       constexpr int TPI = 8;   // tiles per wave and unit: their 32 loads of P are in flight together (one tile at a time
                                // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
-      // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a tile
-      // below it also writes its result to the mirror position (32-byte pieces, four per 128-byte line); a diagonal tile
-      // forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
+      // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a diagonal
+      // tile forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
       // Work unit of a wave: TPI vertically adjacent tiles of one column block (rows 16 ti0 .. +127): its loads cover 1024
       // contiguous bytes per column (HBM likes long runs: 128-byte runs scattered over the matrix reached 2.8 TB/s).  Units
       // are numbered column block by column block over the lower triangle and dealt to the waves round-robin.
@@ -952,9 +938,7 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
           for (int rg = 0; rg < 4; rg++) {
             const int j = 16 * tj + lk + 4 * rg;
             if (ti < nt && i < nact && j < nact) {
-              P[i + (long)j * ld] = pv[q][rg];
-              // the mirror tile (column block ti): only where somebody reads it before the next full symmetrisation
-              if (ti != tj && (((need >> ti) & 1u) || (tj >= 1 && (ti - 1) / 3 == (tj - 1) / 3))) P[j + (long)i * ld] = pv[q][rg];
+              P[i + (long)j * ld] = pv[q][rg];   // (no mirror store: nothing reads above the diagonal, see the panel load)
             }
           }
         }
