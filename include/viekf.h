@@ -246,6 +246,14 @@ int viekf_batch_restore_filters(viekf_batch *b, const int32_t *slot, viekf_mem w
  *  handed to snapshot_filters / restore_filters in DEVICE memory cannot be checked by the host: an out-of-range one is skipped
  *  and that filter's VIEKF_FLAG_INTERNAL is raised.) */
 int viekf_batch_propagate_to(viekf_batch *b, const double *u, const double *dt, int32_t dst_slot, viekf_mem where);
+/* K propagates in a row, step k into ring slot dst_slots[k] (all different, none of them the live slot); the last one becomes the
+ * live state.  u [K][batch][6], dt [K][batch], 1 <= K <= 64.  This is the replay after a rewind (src/vi_ekf/vi_ekf_meas.cpp:106-118:
+ * propagate_state(u, t, false) for every stored input).  Where the fused kernel applies it is ONE launch and only the LAST slot is
+ * written -- *intermediates_written = 0: slots dst_slots[0 .. K-2] keep their old contents and the caller has to treat them as
+ * unknown (viekf_seq_* re-creates such a slot from the nearest written one if a later measurement rewinds to it); otherwise the
+ * steps run one by one, every slot is written and *intermediates_written = 1.  The final state is the same either way. */
+int viekf_batch_propagate_n_to(viekf_batch *b, int32_t K, const double *u, const double *dt, const int32_t *dst_slots,
+                               int32_t *intermediates_written, viekf_mem where);
 
 /* ONE measurement of any model of the reference's table per filter: VIEKF::update with
  * h_acc/h_alt/h_att/h_pos/h_vel/h_qzeta/h_feat/h_depth/h_inv_depth, src/vi_ekf/vi_ekf_meas.cpp:196-386.

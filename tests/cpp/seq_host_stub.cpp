@@ -76,6 +76,23 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   b->live = dst;
   return VIEKF_OK;
 }
+// the fused form: only the LAST slot is written (the stub poisons the ones in between, as stale device memory would be wrong)
+int viekf_batch_propagate_n_to(viekf_batch* b, int32_t K, const double* u, const double* dt, const int32_t* dst, int32_t* written, viekf_mem) {
+  if (K < 1 || K > 64 || b->active_on) return VIEKF_ERR_INVALID;
+  for (int k = 0; k < K; k++)
+    if (dst[k] < 0 || dst[k] >= (int)b->rx.size() || dst[k] == b->live) return VIEKF_ERR_INVALID;
+  b->calls++;
+  int cur = b->live;
+  for (int k = 0; k < K; k++) {
+    prop(b, cur, dst[K - 1], u + (size_t)6 * b->B * k, dt + (size_t)b->B * k);
+    cur = dst[K - 1];
+  }
+  for (int k = 0; k + 1 < K; k++)
+    for (size_t e = 0; e < b->rx[(size_t)dst[k]].size(); e++) b->rx[(size_t)dst[k]][e] = NAN;
+  b->live = dst[K - 1];
+  if (written) *written = K == 1 ? 1 : 0;
+  return VIEKF_OK;
+}
 int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot, int32_t M, const double* R, int32_t, int32_t* result, viekf_mem) {
   b->calls++;
   for (int i = 0; i < b->B; i++)

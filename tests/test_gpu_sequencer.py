@@ -16,7 +16,7 @@ def _params(seed, identity_qbu=False):
 
 
 def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64, log_root=None, log_filter=0, frames=False,
-         want_gated=True):
+         want_gated=True, late_alt=None):
     """frames=True: every camera frame goes in through ONE viekf_seq_add_frame call (one queue entry per frame) instead of one
     add_measurement per feature; want_gated=False: handle_measurements() without the optional list (nothing waited for)"""
     import vi_ekf_amd as v
@@ -62,6 +62,14 @@ def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=
                 if want_gated:
                     gated_g[b] += gg[b]
                 gated_o[b] += os_[b].handle_measurements()
+        if late_alt is not None and k % 7 == 5 and k > 7:   # a second, slower sensor: its reading is stamped INSIDE the span the
+            tz = t - late_alt                                # last frame's replay covered
+            alt = rng.normal(2.0, 0.05, (B, 1))
+            sg.add_measurement(tz, alt, orc.ALT, np.array([[0.01]]), True)
+            sg.handle_measurements(want_gated=False)
+            for b in range(B):
+                os_[b].add_measurement(tz, alt[b], orc.ALT, np.array([[0.01]]), True)
+                os_[b].handle_measurements()
     return g, sg, os_, gated_g, gated_o
 
 
@@ -81,6 +89,23 @@ def test_sequencer_matches_reference_plumbing(delay):
     st = sg.status()
     assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
     assert st["queued"] == len(os_[0].zbuf) and st["inputs"] == len(os_[0].u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delay,late", [(0.03, 0.010), (0.03, 0.0185), (0.0105, 0.006)])
+def test_rewind_into_a_fused_replay(delay, late):
+    """The replay that closes handle_measurements runs as ONE fused launch and writes only its last ring slot
+    (viekf_batch_propagate_n_to); a later measurement stamped inside that span makes the sequencer re-create the slot it rewinds to
+    from the nearest written one.  Against the restated reference plumbing, which keeps every slot."""
+    B, N = 3, 6
+    g, sg, os_, gg, go = _run(B, N, seed=11, delay=delay, frames=True, late_alt=late)
+    for b in range(B):
+        assert sg.tracked_features()[b] == list(os_[b].f.feature_ids)
+    assert_close(g.get_state(), np.stack([o.f.x for o in os_]), "x")
+    assert_close(g.get_covariance(), np.stack([o.f.P for o in os_]), "P")
+    assert gg == go
+    st = sg.status()
+    assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
 
 
 @pytest.mark.gpu

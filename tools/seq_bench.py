@@ -31,9 +31,12 @@ def run(B=1024, N=50, independent=False, frames=12, per_feature=False, delay=0.0
     pending = []          # (arrival time, stamp, frame index)
     torch.cuda.synchronize()
     t0 = None
+    host = {"propagate": 0.0, "add_frame": 0.0, "handle": 0.0}   # time spent INSIDE the calls (they only queue device work)
     while nframes < frames + 2:
         t = k * dt
+        h0 = time.perf_counter()
         s.propagate_state(sc["u"][k % 32], t)
+        host["propagate"] += time.perf_counter() - h0
         imu += 1
         if t >= next_cam:
             pending.append((next_cam + delay, next_cam, k))
@@ -45,18 +48,23 @@ def run(B=1024, N=50, independent=False, frames=12, per_feature=False, delay=0.0
                 for i in range(N):
                     s.add_measurement(stamp, zf[:, i, :], 6, R, True, int(i))
             else:
+                h0 = time.perf_counter()
                 s.add_frame(stamp, zf, R, ids)
+                host["add_frame"] += time.perf_counter() - h0
+            h0 = time.perf_counter()
             s.handle_measurements(want_gated=False)
+            host["handle"] += time.perf_counter() - h0
             nframes += 1
             if nframes == 2:          # warm-up done
                 g.sync()
                 t0, imu = time.perf_counter(), 0
+                host = {k2: 0.0 for k2 in host}
         k += 1
     g.sync()
     secs = time.perf_counter() - t0
     st = g.get_status()
     return {"imu_steps_per_s": B * imu / secs, "frames_per_s": B * (nframes - 2) / secs, "imu_steps": imu, "frames": nframes - 2,
-            "seconds": secs, "bad_filters": int((st & (1 | 2 | 8) != 0).sum()),
+            "seconds": secs, "host_seconds_in_calls": {k2: round(v2, 5) for k2, v2 in host.items()}, "bad_filters": int((st & (1 | 2 | 8) != 0).sum()),
             "what": "B=%d N=%d, %s clock, 250 Hz IMU : 30 Hz frames stamped %.0f ms back (rewind + replay every frame), %s"
                     % (B, N, "one per filter" if independent else "shared", delay * 1e3,
                        "one add_measurement per feature" if per_feature else "viekf_seq_add_frame")}

@@ -23,7 +23,7 @@ SYMBOLS = [
     "viekf_batch_sync", "viekf_batch_set_kernel", "viekf_batch_get_state", "viekf_batch_set_state",
     "viekf_batch_get_status", "viekf_batch_propagate", "viekf_batch_init_feature", "viekf_batch_update_feat",
     "viekf_batch_step", "viekf_batch_update", "viekf_batch_keep_features", "viekf_batch_history_resize",
-    "viekf_batch_snapshot", "viekf_batch_restore", "viekf_batch_keyframe_reset", "viekf_batch_get_params", "viekf_batch_select", "viekf_batch_propagate_to",
+    "viekf_batch_snapshot", "viekf_batch_restore", "viekf_batch_keyframe_reset", "viekf_batch_get_params", "viekf_batch_select", "viekf_batch_propagate_to", "viekf_batch_propagate_n_to",
     "viekf_seq_create", "viekf_seq_destroy", "viekf_seq_propagate", "viekf_seq_add_measurement",
     "viekf_seq_handle_measurements", "viekf_seq_keep_only_features", "viekf_seq_tracked_features", "viekf_seq_status",
     "viekf_batch_eval_xdot", "viekf_batch_eval_h", "viekf_batch_get_cov_diag", "viekf_seq_init_logger",
@@ -139,6 +139,7 @@ def lib():
         L.viekf_batch_keyframe_reset.argtypes = [_vp, _vp, _vp, C.c_int]
         L.viekf_batch_select.argtypes = [_vp, C.c_int32]
         L.viekf_batch_propagate_to.argtypes = [_vp, _vp, _vp, C.c_int32, C.c_int]
+        L.viekf_batch_propagate_n_to.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int]
         L.viekf_batch_eval_xdot.argtypes = [_vp, _vp, _vp, C.c_int]
         L.viekf_batch_eval_h.argtypes = [_vp, C.c_int32, _vp, _vp, C.c_int]
         L.viekf_batch_get_cov_diag.argtypes = [_vp, _vp, C.c_int]

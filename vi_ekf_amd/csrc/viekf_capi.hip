@@ -89,6 +89,7 @@ struct viekf_batch {
   // viekf_batch_set_tuning (tests / experiments; the defaults are what a caller gets)
   // async host inputs (viekf_batch_set_async): pinned staging ring the arguments are copied into at call time
   bool async_host = false;
+  char* d_pin = nullptr;       // the device's address of h_pin
   char* h_pin = nullptr;
   size_t pin_bytes = 0, pin_used = 0;
   int tile_inst = -1;          // tile family (P as MFMA accumulator tiles): index into kTileInst, -1 = not used for this batch
@@ -115,6 +116,8 @@ StreamArgs make_args(const viekf_batch* b) {
   return a;
 }
 
+constexpr size_t kZeroCopyBytes = 4u << 20;
+
 // bump allocator over one device staging region (host-pointer calls only)
 int stage_begin(viekf_batch* b, size_t need) {
   need += 4096;
@@ -133,12 +136,15 @@ int stage_begin(viekf_batch* b, size_t need) {
     // A pinned RING on the host side (the copies out of it run later, in stream order) and a ring on the device side too: the
     // previous call's kernel may still be reading its staged arguments, and although the next call's copy is ordered behind it
     // on the stream, a ring lets the copy engine run ahead.  Both wrap after a stream synchronise.
-    const size_t ring = std::max<size_t>(64 * need, 8u << 20);
+    const size_t ring = std::max<size_t>(64 * need, 64u << 20);   // (a wrap drains the stream: make it rare)
     if (ring > b->pin_bytes) {
       HIP_TRY(hipStreamSynchronize(b->stream));
       if (b->h_pin) HIP_TRY(hipHostFree(b->h_pin));
       b->h_pin = nullptr; b->pin_bytes = 0;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_pin), ring, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_pin), ring, hipHostMallocMapped));
+      void* dp = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dp, b->h_pin, 0));
+      b->d_pin = static_cast<char*>(dp);
       b->pin_bytes = ring; b->pin_used = 0;
     }
     if (b->pin_used + need > b->pin_bytes) {   // wrap: everything queued so far has to have left the ring
@@ -168,6 +174,10 @@ int in_ptr(viekf_batch* b, const Tp* src, size_t count, viekf_mem where, const T
     std::memcpy(b->h_pin + off, src, bytes);
     b->pin_used = off + bytes;
     from = b->h_pin + off;
+    // The kernels read their arguments (an IMU sample and a dt per filter; a frame's pixels and slots: about 1 KB per filter)
+    // straight out of the pinned ring: every workgroup fetches its own few hundred bytes across the host link in its prologue,
+    // which costs the launch less than copy commands between the kernels cost the stream (each one a switch of engines).
+    if (bytes <= kZeroCopyBytes) { *out = reinterpret_cast<const Tp*>(b->d_pin + off); return VIEKF_OK; }
   }
   HIP_TRY(hipMemcpyAsync(d, from, count * sizeof(Tp), hipMemcpyHostToDevice, b->stream));
   *out = d;
@@ -1483,6 +1493,39 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
     if (int rc = viekf_batch_select(b, dst_slot)) return rc;
     if (int rc = launch_propagate(b, d_u, d_dt)) return rc;
   }
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_propagate_n_to(viekf_batch* b, int32_t K, const double* u, const double* dt, const int32_t* dst_slots,
+                               int32_t* intermediates_written, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || !dt || !dst_slots) return fail(VIEKF_ERR_INVALID, "u, dt and dst_slots must not be null");
+  if (K < 1 || K > 64) return fail(VIEKF_ERR_INVALID, "1 <= K <= 64 propagates per call");
+  for (int k = 0; k < K; k++) {
+    if (dst_slots[k] < 0 || dst_slots[k] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+    if (dst_slots[k] == b->live_slot) return fail(VIEKF_ERR_INVALID, "a destination slot is the live slot");
+    for (int j = 0; j < k; j++)
+      if (dst_slots[j] == dst_slots[k]) return fail(VIEKF_ERR_INVALID, "destination slots must differ");
+  }
+  if (intermediates_written) *intermediates_written = 1;
+  if (K == 1 || !use_resident(b) || b->active_on) {   // one slot at a time, every slot written
+    for (int k = 0; k < K; k++)
+      if (int rc = viekf_batch_propagate_to(b, u + (size_t)6 * b->B * k, dt + (size_t)b->B * k, dst_slots[k], where)) return rc;
+    return VIEKF_OK;
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  const double *d_u = nullptr, *d_dt = nullptr;
+  if (where == VIEKF_HOST)
+    if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * b->B * K) + stage_size(sizeof(double) * b->B * K))) return rc;
+  if (int rc = in_ptr(b, u, (size_t)6 * b->B * K, where, &d_u)) return rc;
+  if (int rc = in_ptr(b, dt, (size_t)b->B * K, where, &d_dt)) return rc;
+  const int last = dst_slots[K - 1];
+  // ONE launch of the fused kernel: P is loaded from the live slot, stays on chip through the K propagates and is stored into the
+  // last slot only
+  if (int rc = launch_resident(b, true, d_u, d_dt, nullptr, nullptr, 0, nullptr, 0, nullptr, slot_x(b, last), slot_P(b, last), K)) return rc;
+  if (int rc = viekf_batch_select(b, last)) return rc;
+  if (intermediates_written) *intermediates_written = 0;
   if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }

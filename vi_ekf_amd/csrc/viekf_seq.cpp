@@ -126,6 +126,8 @@ struct viekf_seq {
   int B = 0, N = 0, H = 0, MH = 0;
   viekf_params prm;
   std::vector<double> t;                                           // t_ ring
+  std::vector<uint8_t> mat;                                        // ring slot holds its state (0: a step inside a fused replay --
+                                                                   // its time is known, its state is re-created on demand)
   int i = 0;                                                       // i_
   double start_t = NAN;
   std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [B][6]), newest first
@@ -250,10 +252,75 @@ int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
   if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), ip, VIEKF_HOST)) return rc;   // the old slot stays as history
   s->i = ip;                                                       // :306
   s->t[s->i] = t;
+  s->mat[s->i] = 1;
   if (logging) {
     std::vector<double> x, Pd;
     if (int rc = fetch_state_and_diag(s, x, Pd)) return rc;
     log_state(s, t, x, Pd, s->u.front().second.data() + 6 * (size_t)s->log_filter, xdot.data());
+  }
+  return VIEKF_OK;
+}
+
+// The replay that closes handle_measurements (vi_ekf_meas.cpp:106-118): propagate_state(u, t, false) for the stored inputs
+// u[from], ..., u[0], each to its own time stamp -- as ONE call where the core fuses it (P stays on chip through the whole replay and
+// only the last ring slot is written).  The slots in between keep their time stamps and are marked as not holding their state;
+// materialize() re-creates one from the nearest slot that does if a later, late measurement rewinds into the span.
+int replay_inputs(viekf_seq* s, size_t from) {
+  const int B = s->B;
+  std::vector<size_t> idx;
+  std::vector<double> dtv;
+  double tprev = s->t[s->i];
+  for (size_t k = from + 1; k-- > 0;) {
+    const double dt = s->u[k].first - tprev;
+    if (std::fabs(dt) < 1e-6 || dt < 0) continue;                  // propagate_core makes no step then (vi_ekf.cpp:281-289)
+    idx.push_back(k); dtv.push_back(dt); tprev = s->u[k].first;
+  }
+  size_t done = 0;
+  while (done < idx.size()) {
+    const int K = (int)std::min<size_t>(std::min<size_t>(64, idx.size() - done), (size_t)std::max(1, s->H - 1));
+    if (K == 1) {
+      if (int rc = propagate_core(s, s->u[idx[done]].second.data(), s->u[idx[done]].first, false)) return rc;
+      done++;
+      continue;
+    }
+    std::vector<double> U((size_t)K * B * 6), DT((size_t)K * B);
+    std::vector<int32_t> slots(K);
+    for (int k = 0; k < K; k++) {
+      std::memcpy(U.data() + (size_t)k * B * 6, s->u[idx[done + k]].second.data(), sizeof(double) * 6 * (size_t)B);
+      std::fill(DT.begin() + (size_t)k * B, DT.begin() + (size_t)(k + 1) * B, dtv[done + k]);
+      slots[k] = (s->i + 1 + k) % s->H;
+    }
+    int32_t written = 1;
+    if (int rc = viekf_batch_propagate_n_to(s->core, K, U.data(), DT.data(), slots.data(), &written, VIEKF_HOST)) return rc;
+    for (int k = 0; k < K; k++) {
+      s->t[slots[k]] = s->u[idx[done + k]].first;
+      s->mat[slots[k]] = (written || k == K - 1) ? 1 : 0;
+    }
+    s->i = slots[K - 1];
+    done += (size_t)K;
+  }
+  return VIEKF_OK;
+}
+
+// makes ring slot `target` the live state (the rewind, vi_ekf_meas.cpp:50-52); a slot inside a fused replay is first re-created:
+// back to the nearest slot that holds its state, then forward step by step with the inputs those steps were made with
+int rewind_to(viekf_seq* s, int target) {
+  int jv = target, back = 0;
+  while (!s->mat[jv] && back < s->H) { jv = (jv + s->H - 1) % s->H; back++; }
+  if (!s->mat[jv]) return VIEKF_ERR_INVALID;
+  if (jv != s->i) {
+    if (int rc = viekf_batch_select(s->core, jv)) return rc;
+    s->i = jv;
+  }
+  for (int q = 1; q <= back; q++) {
+    const int slot = (jv + q) % s->H;
+    const double tq = s->t[slot];
+    const std::vector<double>* uq = nullptr;
+    for (const auto& e : s->u)
+      if (e.first == tq) { uq = &e.second; break; }
+    if (!uq) return VIEKF_ERR_INVALID;                            // (inputs and ring have the same depth: the step's input is there)
+    if (int rc = propagate_core(s, uq->data(), tq, false)) return rc;   // writes slot (i + 1) % H = `slot`, marks it
+    if (s->i != slot) return VIEKF_ERR_INVALID;
   }
   return VIEKF_OK;
 }
@@ -595,6 +662,7 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   if (int rc = viekf_batch_select(core, 0)) { delete s; return rc; }
   s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
   s->t.assign(state_hist, NAN);                                    // vi_ekf.cpp:22-27
+  s->mat.assign(state_hist, 1);
   s->ids.assign(B, {});
   s->slot_of.assign(B, {});
   s->next_id.assign(B, 0);
@@ -901,11 +969,10 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     s->zbuf.erase(s->zbuf.begin() + zi);
     return finish();
   }
-  if (target != s->i) {   // rewind = the ring slot becomes the live state (:50-52); feature counts are not part of the ring
-    if (int rc = viekf_batch_select(s->core, target)) return rc;
-    s->i = target;
-  }
+  if (target != s->i)     // rewind = the ring slot becomes the live state (:50-52); feature counts are not part of the ring
+    if (int rc = rewind_to(s, target)) return rc;
   std::vector<int32_t> res;
+  size_t tail = 0;
   ui--;                                                            // :74
   while (ui != 0) {                                                // :75
     bool left_inner_by_break = false;
@@ -949,18 +1016,16 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
           if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;
           ui--;
         }
-      } else {                                                     // :106-115
-        while (ui != 0) {
-          if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;
-          ui--;
-        }
+      } else {                                                     // :106-115: every remaining input, down to u[1] ...
+        tail = ui;
+        ui = 0;
         left_inner_by_break = true;
         break;
       }
     }
     if (!left_inner_by_break) break;   // (the inner condition can only fail with ui == 0)
   }
-  if (int rc = propagate_core(s, s->u[ui].second.data(), s->u[ui].first, false)) return rc;   // :118
+  if (int rc = replay_inputs(s, tail)) return rc;                  // ... and u[0] (:118), fused into one launch where possible
   {   // :121-122 (the reference counts measurements: a frame block weighs its `count`)
     long total = 0;
     for (const auto& e : s->zbuf) total += e.count;
