@@ -131,7 +131,8 @@ int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
  *                            instance does not hold num_features; the automatic choice is then restored)
  *   VIEKF_TUNE_UNIT_LAMBDA   0 = never the instances specialised for lambda_feat = [1, 1, x]
  *   VIEKF_TUNE_BLOCK_GROUP   measurements per pass of the grouped wide-P update: 0 = automatic, 16, 24, 32 (used where it fits the LDS)
- *   VIEKF_TUNE_STREAM_MFMA   0 = the streaming kernels without matrix-core passes (one pass over P per measurement)
+ *   VIEKF_TUNE_STREAM_MFMA   0 = the streaming kernels without matrix-core passes (one pass over P per measurement), 1 = with
+ *                            them (default), 2 = with them but the propagate in r02's form (operands staged in global scratch)
  *   VIEKF_TUNE_TILES         the tile family of the fused step (P as fp64-MFMA accumulator tiles, N = 46..50): 0 / 1 = not used
  *                            (the default: the resident family measures faster on the MI355X at every batch size), 2 = its
  *                            one-filter-per-workgroup form, 3 = its paired form (two filters per workgroup) */

@@ -31,7 +31,7 @@ def counter(sub, name):
         if r["Counter_Name"] != name or "viekf::k_" not in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].split("(")[0]
-        if "k_propagate_stream" in k or "k_update_feat" in k:
+        if "k_propagate_" in k or "k_update_feat" in k:
             acc.setdefault(k, []).append(float(r["Counter_Value"]))
     return {k: {"launches": len(v), "mean_kb": sum(v) / len(v)} for k, v in acc.items()}
 

@@ -16,6 +16,7 @@
 #include "viekf_host.hpp"
 #include "viekf_instances.hpp"
 #include "viekf_kernels_hooks.hpp"
+#include "viekf_kernels_wide.hpp"
 
 // (the fused-step kernels are compiled in viekf_inst.hip, one object file per group of instances)
 #define RES_EXT(RB, NW, NS) VIEKF_RES_FLAVOURS(extern, RB, NW, NS)
@@ -215,8 +216,22 @@ int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
   if (int rc = ensure_full_P(b, stream_mfma_ok(b) ? 2 : 0)) return rc;
   StreamArgs a = make_args(b);
   if (stream_mfma_ok(b)) {   // feature/feature part on the fp64 matrix cores: reads and writes the lower triangle only
-    hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2),
-                       b->stream, a, d_u, d_dt);
+    const size_t wlds = sizeof(double) * (size_t)WideLds(b->N, b->nxs).total;
+    if (b->tune_stream_mfma != 2 && 3 * b->N <= 512 && wlds <= 158 * 1024) {   // the K = 24 record form, records in LDS
+      {
+        std::lock_guard<std::mutex> lk(g_attr_mutex);
+        static size_t have[64] = {};
+        size_t& hw = have[b->device & 63];
+        if (wlds > hw) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_propagate_wide<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+          hw = wlds;
+        }
+      }
+      hipLaunchKernelGGL((k_propagate_wide<512>), dim3(b->B), dim3(512), wlds, b->stream, a, d_u, d_dt);
+    } else {                                                                    // r02's K = 38 form, operands staged in global scratch
+      hipLaunchKernelGGL((k_propagate_stream<512, true>), dim3(b->B), dim3(512), lds_propagate(b) + sizeof(double) * (9 * (size_t)b->N + 2),
+                         b->stream, a, d_u, d_dt);
+    }
     b->upper_stale = 2;
     b->stale_ever = 2;
   } else
@@ -858,8 +873,8 @@ int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
   } else {
     const int bg = blocked_group(b, nullptr);
     if (bg > 0)
-      snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_blocked<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
-               "passes, lower triangle only)", bg, bg);
+      snprintf(buf, sizeof buf, "%s + k_update_feat_blocked<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
+               "passes, lower triangle only)", (b->tune_stream_mfma != 2 && 3 * b->N <= 512) ? "k_propagate_wide (K = 24 records in LDS)" : "k_propagate_stream", bg, bg);
     else
       snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_stream (P in HBM/L2, one pass per measurement)");
   }
@@ -930,7 +945,8 @@ int viekf_batch_set_tuning(viekf_batch* b, int32_t key, int32_t value) {
       HIP_TRY(hipStreamSynchronize(b->stream));
       return setup_tiles(b);
     case VIEKF_TUNE_STREAM_MFMA:
-      b->tune_stream_mfma = value != 0;
+      if (value < 0 || value > 2) return fail(VIEKF_ERR_INVALID, "stream MFMA: 0 off, 1 on, 2 on with r02's scratch-staged propagate");
+      b->tune_stream_mfma = value;
       if (!b->tune_stream_mfma) { if (int rc = ensure_full_P(b)) return rc; }   // (the plain kernels read all of P)
       return VIEKF_OK;
     default:
