@@ -143,6 +143,51 @@ def test_propagate_to_ring_slot_equals_in_place(N, kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,kernel,K", [(12, 0, 4), (50, 0, 8), (12, 1, 3), (90, 0, 3), (50, 3, 5)])
+def test_propagate_n_to_equals_k_propagate_to_calls(N, kernel, K):
+    """viekf_batch_propagate_n_to (the closing replay of handle_measurements): K propagates into K ring slots.  The fused family
+    does it in ONE launch, writes only the last slot (intermediates_written = 0, the others keep their old contents) and ends
+    bit for bit where K viekf_batch_propagate_to calls end; the HBM-path family runs the steps one by one and writes every slot.
+    Bad arguments (a repeated slot, the live slot, a slot out of range, K out of range) are refused before anything is touched."""
+    import ctypes as C
+    from vi_ekf_amd import capi
+    from tests.helpers import apply_kernel
+    B = 3
+    sc = scene.make_scene(B, N, K, seed=31 + N)
+    ga, gb = v.BatchVIEKF(B, N, sc["params"]), v.BatchVIEKF(B, N, sc["params"])
+    L = capi.lib()
+    for g in (ga, gb):
+        apply_kernel(g, kernel)
+        for i in range(N):
+            g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        g.history_resize(K + 2)
+        g.snapshot(0)
+        capi.check(L.viekf_batch_select(g._h, 0))
+    u = np.ascontiguousarray(sc["u"][:K]); dt = np.ascontiguousarray(np.tile(sc["dt"], (K, 1)) * (1.0 + 0.1 * np.arange(K))[:, None])
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    for k in range(K):
+        capi.check(L.viekf_batch_propagate_to(ga._h, p(u[k]), p(dt[k]), k + 1, capi.HOST))
+    slots = np.arange(1, K + 1, dtype=np.int32)
+    written = C.c_int32(-1)
+    x0, P0 = gb.get_state(), gb.get_covariance()
+    for bad in (np.array([1, 1] + list(range(2, K)), dtype=np.int32)[:K], np.array([0] + list(range(2, K + 1)), dtype=np.int32)[:K],
+                np.array(list(range(1, K)) + [K + 2], dtype=np.int32)):
+        assert L.viekf_batch_propagate_n_to(gb._h, K, p(u), p(dt), p(bad), C.byref(written), capi.HOST) == capi.ERR_INVALID
+    assert L.viekf_batch_propagate_n_to(gb._h, 65, p(u), p(dt), p(slots), C.byref(written), capi.HOST) == capi.ERR_INVALID
+    assert np.array_equal(gb.get_state(), x0) and np.array_equal(gb.get_covariance(), P0)
+    capi.check(L.viekf_batch_propagate_n_to(gb._h, K, p(u), p(dt), p(slots), C.byref(written), capi.HOST))
+    fused = "k_step_" in gb.describe()
+    assert written.value == (0 if fused else 1)
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+    capi.check(L.viekf_batch_select(gb._h, 0))       # the slot the replay started from is untouched
+    assert np.array_equal(gb.get_state(), x0) and np.array_equal(gb.get_covariance(), P0)
+    if not fused:                                    # every slot written: the same as the step-by-step batch, slot by slot
+        for k in range(1, K + 1):
+            capi.check(L.viekf_batch_select(ga._h, k)); capi.check(L.viekf_batch_select(gb._h, k))
+            assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,kernel,K", [(12, 2, 5), (50, 2, 9), (20, 2, 3), (12, 1, 4), (55, 2, 4), (66, 2, 3), (50, 3, 9), (47, 3, 2), (50, 5, 9), (48, 5, 3)])
 def test_step_n_equals_k_propagates_and_a_step(N, kernel, K):
     """viekf_batch_step_n: K IMU samples and the frame's updates in one launch (P stays on chip in the fused kernel) --
