@@ -358,7 +358,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import seq_bench
-            seq_cad = {"shared_clock": seq_bench.run(B, N, False, 10), "independent_clocks": seq_bench.run(B, N, True, 5)}
+            seq_cad = {"shared_clock": seq_bench.run(B, N, False, 40), "independent_clocks": seq_bench.run(B, N, True, 5)}
             if cadence is not None:
                 seq_cad["shared_vs_raw_cadence"] = seq_cad["shared_clock"]["imu_steps_per_s"] / cadence["imu_steps_per_s"]
         except Exception as e:
