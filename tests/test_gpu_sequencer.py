@@ -258,7 +258,7 @@ def test_global_pose_and_covariance_through_keyframe_resets(tmp_path):
     assert np.abs(ref[-1, 1:4] - os_[lf].rec["state"][-1]["x"][0:3]).max() > 1e-6   # global != node-relative by now
 
 
-def _feed(sg, sel, B, N, seed, clock0, dt_imu, delay, steps, alt_every=0):
+def _feed(sg, sel, B, N, seed, clock0, dt_imu, delay, steps, alt_every=0, frames=False):
     """one source (rosbag) per filter: its own clock origin, IMU period and camera delay.  `sel` = the filters of the batch
     this source feeds (all others are masked out of its calls); returns nothing -- the sequencer holds the state"""
     rng = np.random.default_rng(seed)
@@ -279,10 +279,15 @@ def _feed(sg, sel, B, N, seed, clock0, dt_imu, delay, steps, alt_every=0):
         sg.propagate_state(u, tt(t), mask=mask)
         if k % 7 == 3:
             tz = t - delay
+            zf = np.zeros((B, N, 2))
             for i in range(N):
                 z = np.zeros((B, 2))
                 z[sel] = pix[i] + rng.normal(0, 0.5, 2)
-                sg.add_measurement(tt(tz), z, orc.FEAT, R, True, id=i, mask=mask)
+                zf[:, i, :] = z
+                if not frames:
+                    sg.add_measurement(tt(tz), z, orc.FEAT, R, True, id=i, mask=mask)
+            if frames:   # the whole frame in one call (independent clocks: every filter's entries go into its queue at once)
+                sg.add_frame(tt(tz), zf, R, np.arange(N), mask=mask)
             if alt_every and k % alt_every == 3:
                 alt = np.zeros((B, 1))
                 alt[sel] = rng.normal(2.0, 0.05)
@@ -291,7 +296,8 @@ def _feed(sg, sel, B, N, seed, clock0, dt_imu, delay, steps, alt_every=0):
 
 
 @pytest.mark.gpu
-def test_independent_clocks_equal_separate_filters_bit_for_bit():
+@pytest.mark.parametrize("frames", [False, True])
+def test_independent_clocks_equal_separate_filters_bit_for_bit(frames):
     """Filters fed from different sources share a batch (north_star: one filter per trajectory / rosbag): different clock
     origins, IMU periods and camera delays (0 and 30 ms) -- per-filter deferral, rewind target and replay length
     (vi_ekf_meas.cpp:6-127 per filter).  Each filter must equal, bit for bit, a batch of one fed the same source."""
@@ -305,7 +311,7 @@ def test_independent_clocks_equal_separate_filters_bit_for_bit():
     # together: one batch, the sources interleaved call by call (each call carries one source's sample, the others masked out)
     g = v.BatchVIEKF(B, N, p)
     sg = v.SeqVIEKF(g, state_hist=64, meas_hist=200, independent=True)
-    gens = [_feed(sg, [b], B, N, steps=steps, **src) for b, src in enumerate(sources)]
+    gens = [_feed(sg, [b], B, N, steps=steps, frames=frames, **src) for b, src in enumerate(sources)]
     live = list(range(B))
     while live:
         for b in list(live):

@@ -137,7 +137,7 @@ int stage_begin(viekf_batch* b, size_t need) {
     // A pinned RING on the host side (the copies out of it run later, in stream order) and a ring on the device side too: the
     // previous call's kernel may still be reading its staged arguments, and although the next call's copy is ordered behind it
     // on the stream, a ring lets the copy engine run ahead.  Both wrap after a stream synchronise.
-    const size_t ring = std::max<size_t>(64 * need, 64u << 20);   // (a wrap drains the stream: make it rare)
+    const size_t ring = std::max<size_t>(64 * need, 8u << 20);   // (a wrap drains the stream: 64 calls of this size apart)
     if (ring > b->pin_bytes) {
       HIP_TRY(hipStreamSynchronize(b->stream));
       if (b->h_pin) HIP_TRY(hipHostFree(b->h_pin));
@@ -1441,9 +1441,17 @@ int viekf_batch_set_active(viekf_batch* b, const uint8_t* mask, viekf_mem where)
   HIP_TRY(hipSetDevice(b->device));
   if (!mask) { b->active_on = false; return VIEKF_OK; }
   if (!b->d_active) HIP_TRY(hipMalloc(&b->d_active, (size_t)b->B));
-  HIP_TRY(hipMemcpyAsync(b->d_active, mask, (size_t)b->B, where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+  const void* from = mask;
+  if (where == VIEKF_HOST && b->async_host) {   // through the pinned ring: nothing to wait for (the mask itself stays a DEVICE copy:
+    if (int rc = stage_begin(b, stage_size((size_t)b->B))) return rc;   // it outlives any number of launches)
+    const size_t off = (b->pin_used + 255) & ~size_t(255);
+    std::memcpy(b->h_pin + off, mask, (size_t)b->B);
+    b->pin_used = off + (size_t)b->B;
+    from = b->h_pin + off;
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_active, from, (size_t)b->B, where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                          b->stream));
-  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));   // (the caller's buffer may go away)
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));   // (the caller's buffer may go away)
   b->active_on = true;
   return VIEKF_OK;
 }
@@ -1460,7 +1468,10 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, in
       if (slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
   if (!to_ring) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   const int* d_slot = slot;
-  if (where == VIEKF_HOST) {
+  if (where == VIEKF_HOST && b->async_host) {   // (read by this one launch: straight from the pinned ring, nothing to wait for)
+    if (int rc = stage_begin(b, stage_size(sizeof(int) * (size_t)b->B))) return rc;
+    if (int rc = in_ptr(b, slot, (size_t)b->B, where, &d_slot)) return rc;
+  } else if (where == VIEKF_HOST) {
     if (!b->d_ringslot) HIP_TRY(hipMalloc(&b->d_ringslot, sizeof(int) * (size_t)b->B));
     HIP_TRY(hipMemcpyAsync(b->d_ringslot, slot, sizeof(int) * (size_t)b->B, hipMemcpyHostToDevice, b->stream));
     d_slot = b->d_ringslot;
@@ -1468,7 +1479,7 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, viekf_mem where, in
   StreamArgs a = make_args(b);
   hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->h_x, b->h_P, d_slot, to_ring, b->hist_depth);
   HIP_TRY(hipGetLastError());
-  if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }
 int viekf_batch_snapshot_filters(viekf_batch* b, const int32_t* slot, viekf_mem where) { return ring_filters(b, slot, where, 1); }

@@ -890,6 +890,61 @@ int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int3
     }
     return VIEKF_OK;
   }
+  if (s->indep && count > 1) {
+    // independent clocks: the same per-feature tests in the same order (viekf_seq_add_measurement_t), but every filter's accepted
+    // entries go into its queue in ONE insertion -- entry by entry each insert moves the frame's earlier entries (same time stamp:
+    // the new one goes behind them, vi_ekf_meas.cpp:150-156), 50 x 1024 shifts of a few KB per frame
+    std::vector<std::vector<FMeas>> add(B);
+    std::vector<uint8_t> newf(B);
+    std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
+    std::vector<int32_t> ok(B);
+    for (int k = 0; k < count; k++) {
+      bool any_new = false;
+      for (int b = 0; b < B; b++) {
+        const size_t e = (size_t)b * count + k;
+        newf[b] = 0;
+        if (result) result[e] = VIEKF_MEAS_SKIPPED;
+        if (mask && !mask[b]) continue;
+        FilterSeq& f = s->fs[b];
+        const double tb = t_per_filter ? t_per_filter[b] : t;
+        int32_t r = VIEKF_MEAS_SUCCESS;
+        if (tb < f.start_t) r = VIEKF_MEAS_INVALID;                                   // :133-134
+        else if (std::isnan(z[2 * e]) || std::isnan(z[2 * e + 1])) r = VIEKF_MEAS_NAN;   // :136-137
+        else if (id[e] >= 0 && local_id(s, b, id[e]) < 0) {                            // :140-147
+          r = VIEKF_MEAS_NEW_FEATURE;
+          if ((int)s->ids[b].size() < s->N) { newf[b] = 1; any_new = true; }          // vi_ekf_feat.cpp:9-10
+        } else {
+          FMeas m;
+          m.t = tb; m.type = VIEKF_FEAT; m.zdim = 2; m.rdim = 2; m.active = active != 0; m.handled = false; m.id = id[e];
+          std::memset(m.z, 0, sizeof m.z);
+          std::memset(m.R, 0, sizeof m.R);
+          m.z[0] = z[2 * e]; m.z[1] = z[2 * e + 1];
+          std::memcpy(m.R, R, sizeof(double) * 4);
+          add[b].push_back(m);
+        }
+        if (result) result[e] = r;
+      }
+      if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
+        for (int b = 0; b < B; b++) {
+          const size_t e = (size_t)b * count + k;
+          zk[2 * (size_t)b] = z[2 * e]; zk[2 * (size_t)b + 1] = z[2 * e + 1];
+          dk[b] = depth ? depth[e] : NAN;
+        }
+        if (int rc = viekf_batch_init_feature(s->core, zk.data(), dk.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
+        for (int b = 0; b < B; b++)
+          if (newf[b] && ok[b]) push_feature(s, b);
+        if (int rc = refresh_slots(s, newf)) return rc;
+      }
+    }
+    for (int b = 0; b < B; b++) {
+      if (add[b].empty()) continue;
+      FilterSeq& f = s->fs[b];
+      size_t k = 0;                                                                    // :150-156
+      while (k < f.zbuf.size() && !(f.zbuf[k].t < add[b][0].t)) k++;
+      f.zbuf.insert(f.zbuf.begin() + (long)k, add[b].begin(), add[b].end());           // :169-175
+    }
+    return VIEKF_OK;
+  }
   std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
   std::vector<int32_t> ik(B), rk(B);
   for (int k = 0; k < count; k++) {
