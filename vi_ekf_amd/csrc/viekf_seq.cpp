@@ -533,7 +533,7 @@ int refresh_slots(viekf_seq* s, const std::vector<uint8_t>& touched) {
 }
 
 // runs the planned steps: per round the next step of every filter, one masked launch per kind of step
-int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std::vector<int32_t>>& gated) {
+int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std::vector<int32_t>>& gated, bool want_gated) {
   const int B = s->B;
   std::vector<size_t> head(B, 0);
   std::vector<uint8_t> mask(B);
@@ -595,7 +595,8 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
           }
         }
         if (int rc = viekf_batch_set_active(s->core, mask.data(), VIEKF_HOST)) return rc;
-        int rc = viekf_batch_update_feat(s->core, z.data(), sl.data(), M, R.data(), 1, res.data(), VIEKF_HOST);
+        // (nobody asked for the gated ids: no result codes, so the launch is queued and not waited for)
+        int rc = viekf_batch_update_feat(s->core, z.data(), sl.data(), M, R.data(), 1, want_gated ? res.data() : nullptr, VIEKF_HOST);
         (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
         if (rc) return rc;
         for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
@@ -603,7 +604,7 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
         for (int b = 0; b < B; b++) {
           if (!mask[b]) continue;
           const SeqOp& op = ops[b][head[b]];
-          for (size_t j = 0; j < op.meas.size(); j++)
+          for (size_t j = 0; want_gated && j < op.meas.size(); j++)
             if (res[(size_t)b * M + j] == VIEKF_MEAS_GATED) gated[b].push_back(op.meas[j].id);
           done[b] = 1;
         }
@@ -999,7 +1000,7 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
   if (s->indep) {   // every filter plans its own rewind / replay; the device steps run batched by kind
     std::vector<std::vector<SeqOp>> ops(B);
     for (int b = 0; b < B; b++) plan_handle(s, b, ops[b]);
-    if (int rc = run_ops(s, ops, gated)) return rc;
+    if (int rc = run_ops(s, ops, gated, gated_ids != nullptr || gated_count != nullptr)) return rc;
     return finish();
   }
   const bool want_gated = gated_ids != nullptr || gated_count != nullptr;   // (nobody asked: the frame's launch is not waited for)
