@@ -179,6 +179,8 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   }
   const bool partial = prm.use_partial_update != 0;
   int par = 0;  // fix_depth mailbox parity (mirrors the service wave)
+  constexpr int NSV = (T - TW) / 64;   // service waves: with one, the second wave's flag words are not read at all
+  auto fix_word = [&](int mb) -> double { return (NSV > 1) ? S.sm[40 + mb] + S.sm[36 + mb] : S.sm[40 + mb]; };
   RES_STAMP(S, tid == 0, 64);
   __syncthreads();  // B0
   RES_STAMP(S, tid == 0, 65);
@@ -282,7 +284,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     RES_STAMP(S, tid == 0, 70);
     __syncthreads();  // B4p
     for (int e = tk; e < 256; e += TW) { const int r = e >> 4, c = e & 15; Pbb[e] = S.Mbb[min(r, c) * 16 + max(r, c)]; }
-    if (MP && kp + 1 < nkp && own_diag && tid_ < len && (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]) != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
+    if (MP && kp + 1 < nkp && own_diag && tid_ < len && fix_word(par ^ 1) != 0.0) {   // this propagate's fix_depth edits of P(rho,rho), before the next
       const int mb = par ^ 1, I = tid_;
       const double ad = S.fixadd[mb * N + I], st = S.fixset[mb * N + I];
       if (ad != 0.0) { pb[0][8] += ad; S.fixadd[mb * N + I] = 0.0; }
@@ -296,6 +298,15 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
 #pragma unroll
   for (int ia = 0; ia < RB; ia++) vb[ia] = blk(tid_, ia, Ib[ia], Jb[ia]);
   const double p0rr = uniform_f64(prm.P0_feat[2]);   // (read here: a global load inside the update loop would put vmcnt waits there)
+  // Lambda of the body block's two elements of this thread's task (one task per thread where 128 threads share the 128 tasks):
+  // constants of the launch, not re-formed from three LDS words in every update
+  auto bb_mask = [&](int r, int c) -> double { const double lr_ = S.lam[r], lc_ = S.lam[c]; return partial ? (lc_ + lr_ - lr_ * lc_) : 1.0; };
+  double bbL0 = 1.0, bbL1 = 1.0;
+  {
+    constexpr int BBT0 = (TW >= 128) ? 128 : TW;
+    const int ib0 = tid - (TW - BBT0);
+    if (ib0 >= 0 && ib0 < 128) { bbL0 = bb_mask(ib0 >> 3, (ib0 & 7) * 2); bbL1 = bb_mask(ib0 >> 3, (ib0 & 7) * 2 + 1); }
+  }
   // applies the pending fix_depth covariance edits of mailbox `mb` to the owned diagonal blocks (diagonal d = 0)
   auto apply_fixes = [&](int mb, double pending) {
     if (pending == 0.0) return;   // nothing posted (the common case); the flag word was read ahead of the barrier
@@ -344,7 +355,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // produced inside its own phase: no hand-shake, no polling, and the publishing sits off every critical path.
   int2 sq = S.mseq[min(m, S.mcap - 1)];
   if (m < S.M) {
-    apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
+    apply_fixes(par ^ 1, fix_word(par ^ 1));
     const int s0 = S.mslot[m];
     extract_cols(s0, S.Praw);                                   // first measurement: buffer 0
     if (sq.y >= 0) extract_cols(sq.y, S.Praw + 2 * n);          // second one: buffer 1
@@ -379,9 +390,9 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     const double* kP = (cnt & 1) ? S.Z : S.Kt;
     const double* wP = kP + 2 * n;
     __builtin_amdgcn_s_setprio(1);
-    const double fixpending = (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]);   // posted before the barrier by the service wave
+    const double fixpending = fix_word(par ^ 1);   // posted before the barrier by the service wave
     const double gflag = S.sm[50 + (cnt & 1)];          // gate verdict of this measurement (service, previous phase)
-    const double nanw = S.sm[44 + cnt % 3] + S.sm[52 + cnt % 3];   // (the second word: a second service wave's rows)
+    const double nanw = (NSV > 1) ? S.sm[44 + cnt % 3] + S.sm[52 + cnt % 3] : S.sm[44 + cnt % 3];   // (the second word: a second service wave's rows)
     sq = S.mseq[min(mnext, S.mcap - 1)];                 // next iteration's table entry (static data)
     RES_STAMP(S, tid == 0 && it_ < 8, 80 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 0);
@@ -451,12 +462,10 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
       for (int ib = it - (TW - BBT); ib >= 0 && ib < 128; ib += BBT) {
         const int br = ib >> 3, bc2 = (ib & 7) * 2;
         double2 bpv = *reinterpret_cast<double2*>(Pbb + br * 16 + bc2);
-        const double blr = S.lam[br];
-        const double2 blc = lds_ld2(S.lam + bc2);
         const double2 kr = lds_ld2(kP + 2 * br), wr = lds_ld2(wP + 2 * br);
         const double2 k0 = lds_ld2(kP + 2 * bc2), w0 = lds_ld2(wP + 2 * bc2);
         const double2 k1 = lds_ld2(kP + 2 * bc2 + 2), w1 = lds_ld2(wP + 2 * bc2 + 2);
-        const double L0 = partial ? (blc.x + blr - blr * blc.x) : 1.0, L1 = partial ? (blc.y + blr - blr * blc.y) : 1.0;
+        const double L0 = (BBT == 128) ? bbL0 : bb_mask(br, bc2), L1 = (BBT == 128) ? bbL1 : bb_mask(br, bc2 + 1);
         const bool up0 = br <= bc2, up1 = br <= bc2 + 1;
         const double2 ka = up0 ? kr : k0, wa = up0 ? w0 : wr;      // (K_lo, W_hi) of element (br, bc2)
         const double2 kb = up1 ? kr : k1, wb = up1 ? w1 : wr;      // ... of element (br, bc2 + 1)
@@ -477,7 +486,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     m = mnext;
   }
   RES_MARK("worker.loop_end");
-  apply_fixes(par ^ 1, (S.sm[40 + (par ^ 1)] + S.sm[36 + (par ^ 1)]));
+  apply_fixes(par ^ 1, fix_word(par ^ 1));
   RES_STAMP(S, tid == 0, 72);
   __syncthreads();  // B5 : every sweep of the LDS-resident body columns is finished
 
