@@ -442,7 +442,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
     // ---- (2) the raw feature rows of the measurement after next (a fix_depth edit touches P(rho,rho) only, never these
     //      columns), into the buffer the service wave is not reading in this phase
     double* rawdst = S.Praw + (cnt & 1) * 2 * n;
-    if (sq.y >= 0 && !RES_ABLATE(S, 4)) extract_cols(sq.y, rawdst);
+    if (sq.y >= 0 && !RES_ABLATE(S, 4) && !(RES_ABLATE(S, 8) && (cnt & 1))) extract_cols(sq.y, rawdst);   // (bit 8: every other phase -- timing of a pairwise hand-over)
     __builtin_amdgcn_s_setprio(0);
     RES_STAMP(S, tid == 0 && it_ < 8, 160 + 4 * it_ + 1);
     RES_STAMP(S, (tid & 63) == 0 && it_ == 3, 192 + 4 * (tid >> 6) + 2);
