@@ -377,7 +377,7 @@ def main():
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_traffic.json"))):
             j = json.load(open(f))
             if j["config"]["batch"] == B and j["config"]["n_feat"] == N and args.kernel in (0, 2):
-                traffic, traffic_src = j["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                traffic, traffic_src = j.get("traffic_bytes_per_launch", j.get("traffic_bytes_per_step")), os.path.relpath(f, ROOT)
     except Exception:
         traffic = None
 
