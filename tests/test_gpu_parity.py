@@ -300,11 +300,12 @@ def test_device_pointer_path_matches_host_path():
     assert np.array_equal(g1.get_covariance(), g2.get_covariance())
 
 
-@pytest.mark.parametrize("N,M", [(64, 4), (150, 3), (51, 51), (150, 40), (160, 35), (160, 160)])
-def test_wide_p_streaming_family(N, M):
+@pytest.mark.parametrize("N,M,prop", [(64, 4, 1), (150, 3, 1), (51, 51, 1), (150, 40, 1), (160, 35, 1), (160, 160, 1), (150, 40, 2), (64, 4, 2)])
+def test_wide_p_streaming_family(N, M, prop):
     """wide covariance (BASELINE config 5: N=150, n=466): the streaming family -- a few updates per step, and enough of them
     for full 16-measurement groups plus a partial one (N=160 is the ABI limit: whole 48-row super-tiles in the propagate,
-    N=150 and N=51 leave partial ones)"""
+    N=150 and N=51 leave partial ones).  prop = 1: the propagate in the K = 24 record form (k_propagate_wide, the default), 2: r02's
+    form with the operand sets in global scratch (VIEKF_TUNE_STREAM_MFMA = 2, kept for A/B runs)"""
     B, steps = 2, 2
     sc = scene.make_scene(B, N, steps, seed=300 + N)
     z = np.ascontiguousarray(sc["z"][:, :, :M, :])
@@ -315,7 +316,10 @@ def test_wide_p_streaming_family(N, M):
         for i in range(N):
             f.init_feature(sc["pix"][b, i], i)
         fs.append(f)
-    g = make_gpu(sc, B, N)
+    g = make_gpu(sc, B, N, kernel=1)     # (N <= 77 would otherwise run on chip)
+    from vi_ekf_amd import capi
+    g.set_tuning(capi.TUNE_STREAM_MFMA, prop)
+    assert ("k_propagate_wide" in g.describe()) == (prop == 1), g.describe()
     for s in range(steps):
         res = g.step(sc["u"][s], sc["dt"], z[s], slot, sc["R"])
         for b in range(B):
