@@ -129,6 +129,126 @@ def rel_err(gpu_x, gpu_P, xr, Pr):
     return max(ex, eP)
 
 
+ORACLE_KEYS = ("x0", "P0", "Qx", "lam", "Qu", "P0_feat", "Qx_feat", "lam_feat", "cam_center", "focal_len", "q_b_c",
+               "p_b_c", "q_b_u", "min_depth", "use_drag_term", "use_partial_update", "use_keyframe_reset")
+
+
+def cadence_parity(g, sc, N, params, uniq, init_filters, step, d_u, d_dt, d_z, d_slot, d_R, d_res, torch, nsample=6):
+    """One 25-sample cycle of the two cadence routes (propagate / step launches; viekf_batch_step_n with K = 8, 8, 9) from freshly
+    initialised filters vs the oracle on a strided sample -> max rel err of each.  Checker leg, never timed."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    B = g.B
+    which = [int(b) for b in np.unique(np.linspace(0, B - 1, nsample).round().astype(int))]
+    dt = float(sc["dt"][0])
+
+    def oracle_cycle(frames_after):
+        """frames_after[k] = the frame index whose updates follow IMU sample k (or None)"""
+        def fly(b):
+            f = orc.OracleFilter(N).init(**{k: params[k] for k in ORACLE_KEYS})
+            for i in range(N):
+                f.init_feature(sc["pix"][b, i], i)
+            for k, (ui, fr) in enumerate(frames_after):
+                if fr is None:
+                    f.propagate(sc["u"][ui, b], dt)
+                else:
+                    f.run_steps(sc["u"][ui, b][None], dt, sc["z"][fr, b][None], sc["slot"][b], sc["R"])
+            return f.x.copy(), f.P.copy()
+        with ThreadPoolExecutor(max_workers=min(len(which), os.cpu_count() or 1)) as ex:
+            r = list(ex.map(fly, which))
+        return np.stack([a for a, _ in r]), np.stack([p for _, p in r])
+
+    # raw route: the launches of the timed loop below (k % 8 == 7: a full step with frame k % uniq's pixels, else a propagate)
+    init_filters()
+    for k in range(25):
+        if k % 8 == 7:
+            step(k)
+        else:
+            g.propagate(d_u[k % uniq], d_dt)
+    torch.cuda.synchronize()
+    xr, Pr = oracle_cycle([(k % uniq, (k % uniq) if k % 8 == 7 else None) for k in range(25)])
+    e_raw = rel_err(g.get_state()[which], g.get_covariance()[which], xr, Pr)
+    # fused route: three viekf_batch_step_n launches, K = 8, 8, 9 (the inputs the timed loop uses)
+    ks = (8, 8, 9)
+    init_filters()
+    plan = []
+    for q, kq in enumerate(ks):
+        idx = [(j + 3 * q) % uniq for j in range(kq)]
+        uu = torch.stack([d_u[i] for i in idx]).contiguous()
+        dd = torch.stack([d_dt for _ in range(kq)]).contiguous()
+        g.step_n(uu, dd, d_z[q % uniq], d_slot, d_R, result=d_res)
+        plan += [(i, None) for i in idx[:-1]] + [(idx[-1], q % uniq)]
+    torch.cuda.synchronize()
+    xf, Pf = oracle_cycle(plan)
+    e_fused = rel_err(g.get_state()[which], g.get_covariance()[which], xf, Pf)
+    return {"raw": e_raw, "fused": e_fused,
+            "what": "one 25-sample cycle of each route vs the oracle on filters %s (x and P)" % which}
+
+
+def secondary_config(v, scene, torch, dev, dev_index, B, N, K, W, parity_steps, parity_filters):
+    """ms per step, steps/s, roofline fraction (own B_alg) and an in-run parity figure of another BASELINE config"""
+    import glob
+    uniq = min(K + W, 8)
+    sc = scene.make_scene(B, N, uniq, seed=0xC0F0 + N)
+    g = v.BatchVIEKF(B, N, sc["params"], device=dev_index)
+    g.use_torch_stream()
+    d_u, d_z = torch.tensor(sc["u"], device=dev), torch.tensor(sc["z"], device=dev)
+    d_dt, d_slot, d_R = torch.tensor(sc["dt"], device=dev), torch.tensor(sc["slot"], device=dev), torch.tensor(sc["R"], device=dev)
+    d_res = torch.empty((B, N), dtype=torch.int32, device=dev)
+    d_pix = torch.tensor(np.ascontiguousarray(sc["pix"].transpose(1, 0, 2)), device=dev)
+    d_nan = torch.full((B,), float("nan"), dtype=torch.float64, device=dev)
+
+    def init_filters():
+        g.reset()
+        for i in range(N):
+            g.init_feature(d_pix[i], d_nan)
+
+    def step(s):
+        g.step(d_u[s % uniq], d_dt, d_z[s % uniq], d_slot, d_R, result=d_res)
+
+    out = {"batch": B, "n_feat": N, "kernel": g.describe()}
+    if parity_filters > 0:
+        which = np.unique(np.linspace(0, B - 1, parity_filters).round().astype(int))
+        init_filters()
+        for s in range(parity_steps):
+            step(s)
+        torch.cuda.synchronize()
+        gx, gP = g.get_state()[which], g.get_covariance()[which]
+        threads = max(1, min(len(which), usable_cpus()[0]))
+        xr, Pr, secs_o = oracle_run(sc, N, sc["params"], which, parity_steps, threads)
+        out["parity_max_rel_err"] = rel_err(gx, gP, xr, Pr)
+        out["parity"] = "%d filters (strided) x %d step(s) vs the dense reference-order oracle, %.1f s on %d threads" % (
+            len(which), parity_steps, secs_o, threads)
+        if out["parity_max_rel_err"] > 1e-6:
+            raise SystemExit("PARITY FAILURE vs oracle (B=%d, N=%d): rel err %.3e" % (B, N, out["parity_max_rel_err"]))
+    init_filters()
+    for s in range(W):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        step(W + s)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    st = g.get_status()
+    b_alg = scene.algorithmic_bytes_per_step(N)
+    achieved = B * K / secs * b_alg / 1e9
+    traffic, src = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_traffic.json"))):
+        try:
+            j = json.load(open(f))
+            if j["config"]["batch"] == B and j["config"]["n_feat"] == N:
+                traffic, src = j.get("traffic_bytes_per_launch", j.get("traffic_bytes_per_step")), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    out.update({"steps": K, "warmup": W, "ms_per_step": secs / K * 1e3, "steps_per_s": B * K / secs,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "alg_bytes_per_step": b_alg * B, "traffic": traffic, "traffic_source": src},
+                "bad_filters": int((st & (1 | 2 | 8) != 0).sum())})
+    g.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +259,9 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cadence run (profiling: keeps the kernel statistics to the timed steps)")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="milliseconds of the same step run untimed BEFORE the W warm-up steps (a GPU that was just handed over idles at "
+                         "low clocks); 0 = none. The figure for the bare command-line contract is always reported too (no_prewarm)")
     ap.add_argument("--cpu-filters", type=int, default=0)
     ap.add_argument("--cpu-steps", type=int, default=0)
     args = ap.parse_args()
@@ -254,43 +377,51 @@ def main():
 
     # ---- phase B: warmup + timed region
     # A GPU that has just been handed over idles at low clocks: the first ~10 ms of launches run 8 % slower (measured: 20 timed
-    # steps after 5 warm-up steps 0.378 ms per step, after 150 more 0.359).  ~60 ms of the same step, untimed and outside the W
-    # warm-up steps the command line asks for (reported as prewarm_steps), then the filters start over.
+    # steps after 5 warm-up steps 0.378 ms per step, after 150 more 0.359).  The region is therefore timed TWICE with exactly the
+    # command line's W warm-up + K timed steps: first as the bare contract has it (reported as `no_prewarm`, comparable with the
+    # r01 / r02 driver figures), then again after --prewarm-ms of the same step (reported as prewarm_steps); `value` is the second.
+    def timed_region(with_events):
+        init_filters()
+        for s in range(W):
+            step(s)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # HIP events on the launch stream bracket GROUPS of launches (an event between every two launches costs the queue a marker
+        # packet and a completion signal per step: measured 4 % of the headline step): every 10th step, four groups for short runs
+        ES = 10 if K >= 40 else max(1, K // 4)
+        marks = [0]
+        ev = [torch.cuda.Event(enable_timing=True)] if with_events else []
+        t0 = time.perf_counter()
+        if with_events:
+            ev[0].record()
+        for s in range(K):
+            step(W + s, d_res_all[s])
+            if with_events and ((s + 1) % ES == 0 or s == K - 1):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append(e)
+                marks.append(s + 1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev, marks
+
+    secs_cold, _, _ = timed_region(False)
+    secs_cold = reduce_times(secs_cold, world)
     prewarm = 0
-    init_filters()
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.06 or prewarm < 3:
-        step(prewarm)
-        prewarm += 1
-        if prewarm % 8 == 0:
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    init_filters()
-    for s in range(W):
-        step(s)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the launch stream bracket GROUPS of launches (an event between every two launches costs the queue a marker
-    # packet and a completion signal per step: measured 4 % of the headline step): every 10th step, four groups for short runs
-    ES = 10 if K >= 40 else max(1, K // 4)
-    marks = [0]
-    ev = [torch.cuda.Event(enable_timing=True)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for s in range(K):
-        step(W + s, d_res_all[s])
-        if (s + 1) % ES == 0 or s == K - 1:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            ev.append(e)
-            marks.append(s + 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    secs = time.perf_counter() - t0
+    if args.prewarm_ms > 0:
+        init_filters()
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3 or prewarm < 3:
+            step(prewarm)
+            prewarm += 1
+            if prewarm % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    secs, ev, marks = timed_region(True)
     alg_bytes = scene.algorithmic_bytes_per_step(N) * B  # one launch processes B filter-steps
     rec = reduce_record(B * K, secs, alg_bytes * K, parity, world)
     secs = rec["seconds"]
@@ -310,6 +441,16 @@ def main():
     cadence = None
     if world == 1 and not args.no_secondary:
         cyc = 4
+        cad_par = None
+        if not args.no_cpu_baseline:
+            # what this leg times, checked first: one 25-sample cycle of both routes from freshly initialised
+            # filters against the oracle (K vo_propagate + the frame's updates) on a strided sample; outside every timed window
+            cad_par = cadence_parity(g, sc, N, params, uniq, init_filters, step, d_u, d_dt, d_z, d_slot, d_R, d_res, torch)
+            if max(cad_par["raw"], cad_par["fused"]) > 1e-6:
+                raise SystemExit("PARITY FAILURE of the cadence routes vs oracle: %s" % cad_par)
+            init_filters()
+            for s in range(W):
+                step(s)
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for c in range(cyc):
@@ -322,6 +463,10 @@ def main():
         tc = time.perf_counter() - tc
         cadence = {"imu_steps_per_s": B * 25 * cyc / tc, "frames_per_s": B * 3 * cyc / tc,
                    "what": "25 propagates : 3 frames of %d feature updates, %d cycles" % (N, cyc)}
+        if cad_par is not None:
+            cadence["parity_max_rel_err"] = cad_par["raw"]
+            cadence["fused_parity_max_rel_err"] = cad_par["fused"]
+            cadence["parity"] = cad_par["what"]
         # the same work with the IMU samples between two frames fused into the frame's launch (viekf_batch_step_n, K = 8, 8, 9)
         try:
             ks = (8, 8, 9)
@@ -370,16 +515,35 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import seq_bench
-            seq_cad = {"shared_clock": seq_bench.run(B, N, False, 40), "independent_clocks": seq_bench.run(B, N, True, 5)}
+            pf = 0 if args.no_cpu_baseline else 5      # frames flown against oracle/seq_oracle.SeqOracle before the timed run
+            seq_cad = {"shared_clock": seq_bench.run(B, N, False, 40, parity_frames=pf),
+                       "independent_clocks": seq_bench.run(B, N, True, 5, parity_frames=pf)}
             if cadence is not None:
                 seq_cad["shared_vs_raw_cadence"] = seq_cad["shared_clock"]["imu_steps_per_s"] / cadence["imu_steps_per_s"]
+        except SystemExit:
+            raise                          # (a parity failure of a timed route fails the run, like the primary leg's)
         except Exception as e:
             seq_cad = {"error": str(e)[:300]}
+
+    # ... and the other single-GPU BASELINE configs (VERDICT r03 missing #3): configs[1] B=256, N=25 and configs[4] B=1024, N=150
+    # (5 warm-up + 20 timed steps), each with its own algorithmic bytes, kernel description and in-run parity figure
+    configs = None
+    if world == 1 and not args.no_secondary and (B, N) == (1024, 50):
+        configs = {}
+        for name, cb, cn, ck, cw, psteps, pfilters in (("b256_n25", 256, 25, 200, 20, 3, 8), ("b1024_n150", 1024, 150, 20, 5, 1, 2)):
+            try:
+                configs[name] = secondary_config(v, scene, torch, dev, dev_index, cb, cn, ck, cw, psteps,
+                                                 0 if args.no_cpu_baseline else pfilters)
+            except SystemExit:
+                raise
+            except Exception as e:
+                configs[name] = {"error": str(e)[:300]}
 
     # per-launch duration of the step's kernels from HIP events on the launch stream
     launch_ms = np.array([ev[i].elapsed_time(ev[i + 1]) / (marks[i + 1] - marks[i]) for i in range(len(ev) - 1)])
     launch_s = float(np.median(launch_ms)) * 1e-3   # (median over the groups of the groups' average launch duration)
-    achieved = alg_bytes / launch_s / 1e9
+    kernel_achieved = alg_bytes / launch_s / 1e9            # from the HIP-event launch duration
+    achieved = rec["steps"] / secs * scene.algorithmic_bytes_per_step(N) / world / 1e9   # steps/s x B_alg, per GPU
 
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (bench.py cannot run the
     # profiler on itself): FETCH_SIZE (x2, gfx950 rule) + WRITE_SIZE, see profiles/<round>/*_pmc_traffic.json
@@ -402,6 +566,8 @@ def main():
             "steps": K,
             "warmup": W,
             "prewarm_steps": prewarm,
+            "no_prewarm": {"ms_per_step": secs_cold / K * 1e3, "value": B * world * K / secs_cold,
+                           "what": "the same W warm-up + K timed steps run first, straight after set-up (no --prewarm-ms)"},
             "ms_per_step": secs / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -414,6 +580,8 @@ def main():
                        "kernel_family": args.kernel},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_from": "value x B_alg(N) per GPU (SURVEY 8d); kernel_* = the same bytes / the median HIP-event launch duration",
+                         "kernel_achieved": kernel_achieved, "kernel_frac": kernel_achieved / HBM_PEAK_GBS,
                          "kernel": ("%s; one fused launch per step, median HIP-event duration per launch %.4f ms"
                                     if desc.startswith(("k_step_resident", "k_step_tiles")) else
                                     "%s; one propagate and one update launch per step, median HIP-event duration of the pair %.4f ms")
@@ -443,6 +611,8 @@ def main():
             out["single_filter_n12"] = single
         if seq_cad is not None:
             out["seq_cadence_250_30"] = seq_cad
+        if configs is not None:
+            out["configs"] = configs
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if not args.no_cpu_baseline:

@@ -15,11 +15,13 @@
 //
 //   reference member (include/vi_ekf.h)                      line      here
 //   VIEKF(), VIEKF(param_file), load(param_file)             243-249   same (+ num_features, device: run-time here)
-//   init() / init(x0, P0, ... 17 arguments)                  250-255   not offered: parameters come from the YAML file (load) --
-//                                                                      the 17-argument form only serves test/jac_test.cpp's fixture
+//   init() / init(x0, P0, ... 17 arguments)                  250-255   same: the 17 values fill a viekf_params (q_b_u = identity, as
+//                                                                      vi_ekf.cpp:64-99 leaves it) and create the filter -- the fixture
+//                                                                      of test/jac_test.cpp:118-170
 //   now()                                                    257-261   same
-//   measurement_functions (public table of h_* pointers)     263       not offered: a table of member-function pointers into Eigen
-//                                                                      signatures; h(type, ...) below is the typed equivalent
+//   measurement_functions (public table of h_* pointers)     263       same: measurement_function_ptr (:68) over the typedef names
+//                                                                      xVector / zVector / hMatrix, filled in the order of
+//                                                                      vi_ekf.cpp:47-61 (h_pixel_vel: the reference's empty TODO)
 //   NaNsInTheHouse / BlowingUp / NegativeDepth               266-268   from the per-filter status word
 //   global_to_local_feature_id, tracked_features             271-272   same
 //   get_depths / get_zetas / get_qzetas / get_zeta           275-278   same (Vec / Mat)
@@ -35,8 +37,9 @@
 //   handle_measurements / add_measurement                    307-308   same
 //   update(measurement_t&)                                   309       not offered: its argument type is private to the class;
 //                                                                      measurements enter through add_measurement
-//   h_acc ... h_inv_depth (x, h, H, id)                      310-318   same names, evaluated on the device; h_pixel_vel (:319) is an
-//                                                                      empty TODO in the reference and is not offered
+//   h_acc ... h_inv_depth (x, h, H, id)                      310-318   same names, evaluated on the device; the feature models map
+//                                                                      the GLOBAL id to the slot like vi_ekf_meas.cpp:346,356,371,381;
+//                                                                      h_pixel_vel (:319) does nothing, like the reference's TODO
 //   propagate_global_covariance                              322       inside get_global_cov / keyframe_reset (viekf_seq.cpp)
 //   keyframe_reset(xm, xp, N) / keyframe_reset()             323-324   same
 //   register_keyframe_reset_callback                         325       same
@@ -47,6 +50,12 @@
 //   log_global_position                                      334       accepted and ignored: it writes to LOG_GLOBAL, a stream the
 //                                                                      reference never opens (vi_ekf_log.cpp:85-97)
 //   fix_depth()                                              337       not offered: runs inside every propagate / update on the device
+// The typedef names of include/vi_ekf.h:53-61 (xVector, dxVector, dxMatrix, dxuMatrix, uVector, zVector, hMatrix) are shim::Vec /
+// shim::Mat here; a caller that has its own (Eigen's fixed-size matrices, the mock of tests/cpp/shim_jactest_callsites.cpp) defines
+// them in namespace vi_ekf and #defines VIEKF_SHIM_TYPES before including this file.  Every OUTPUT argument is a template as
+// well: it is resized where it has resize(rows, cols) and must otherwise already have the right number of coefficients;
+// get_state() / get_covariance() return `const xVector&` / `const dxMatrix&` of whichever types those names stand for.
+// The class is movable, not copyable (test/jac_test.cpp:118,169 returns its filter by value: a move).
 // No exceptions cross this class, like the reference: a failing call prints to std::cerr and ok() turns false.
 #pragma once
 #include <chrono>
@@ -55,6 +64,7 @@
 #include <functional>
 #include <iostream>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -73,6 +83,7 @@ struct Mat {
   int r = 0, c = 0;
   Mat() {}
   Mat(int rows, int cols) : d((size_t)rows * cols, 0.0), r(rows), c(cols) {}
+  void resize(int rows, int cols) { d.assign((size_t)rows * cols, 0.0); r = rows; c = cols; }
   const double* data() const { return d.data(); }
   double* data() { return d.data(); }
   long size() const { return (long)d.size(); }
@@ -106,7 +117,22 @@ struct Vec : Mat {
   }
   Vec topRows(int n) const { return segment(0, n); }
 };
+// an output argument is brought to rows x cols where its type can be resized; fixed-size types are left alone
+template <class T> auto size_to(T& o, int r, int c, int) -> decltype(o.resize(r, c), void()) { o.resize(r, c); }
+template <class T> void size_to(T&, int, int, long) {}
 }  // namespace shim
+
+#ifndef VIEKF_SHIM_TYPES   // reference include/vi_ekf.h:53-61
+typedef shim::Vec xVector;
+typedef shim::Vec dxVector;
+typedef shim::Mat dxMatrix;
+typedef shim::Mat dxuMatrix;
+typedef shim::Vec uVector;
+typedef shim::Vec zVector;
+typedef shim::Mat hMatrix;
+#endif
+class VIEKF;
+typedef void (VIEKF::*measurement_function_ptr)(const xVector& x, zVector& h, hMatrix& H, const int id) const;   // :68
 
 class VIEKF {
  public:
@@ -119,23 +145,43 @@ class VIEKF {
   typedef shim::Vec Vec;
   typedef shim::Mat Mat;
 
-  VIEKF() {}
+  VIEKF() { fill_table(); }
   explicit VIEKF(const std::string& param_file, int num_features = NUM_FEATURES, int device = 0)
-      : num_features_(num_features), device_(device) { load(param_file); }
+      : num_features_(num_features), device_(device) { fill_table(); load(param_file); }
   VIEKF(const VIEKF&) = delete;
   VIEKF& operator=(const VIEKF&) = delete;
+  VIEKF(VIEKF&& o) noexcept { fill_table(); take(o); }
+  VIEKF& operator=(VIEKF&& o) noexcept { if (this != &o) { release(); take(o); } return *this; }
   ~VIEKF() { release(); }
+
+  std::vector<measurement_function_ptr> measurement_functions;             // include/vi_ekf.h:263, filled as vi_ekf.cpp:47-61
+
+  void init() {}                                                          // :250 (the constructor's reset: nothing is held before load / init)
+  // init(x0, P0, ...), vi_ekf.cpp:64-99: the filter from 17 values instead of a parameter file (test/jac_test.cpp:154)
+  template <class X0, class PV, class QV, class LV, class QU, class F1, class F2, class F3, class C2, class FL, class QC, class PC>
+  void init(const X0& x0, const PV& P0, const QV& Qx, const LV& lambda, const QU& Qu, const F1& P0_feat, const F2& Qx_feat,
+            const F3& lambda_feat, const C2& cam_center, const FL& focal_len, const QC& q_b_c, const PC& p_b_c, double min_depth,
+            bool use_drag_term, bool use_partial_update, bool use_keyframe_reset, double keyframe_overlap_threshold) {
+    release();
+    viekf_params p;
+    viekf_params_default(&p);                                             // (q_b_u stays the identity: init() never sets q_b_u_)
+    auto put = [](double* dst, const double* src, int k) { for (int i = 0; i < k; i++) dst[i] = src[i]; };
+    put(p.x0, x0.data(), 17); put(p.P0, P0.data(), 16); put(p.Qx, Qx.data(), 16); put(p.lambda, lambda.data(), 16);
+    put(p.Qu, Qu.data(), 6); put(p.P0_feat, P0_feat.data(), 3); put(p.Qx_feat, Qx_feat.data(), 3); put(p.lambda_feat, lambda_feat.data(), 3);
+    put(p.cam_center, cam_center.data(), 2); put(p.focal_len, focal_len.data(), 2); put(p.q_b_c, q_b_c.data(), 4); put(p.p_b_c, p_b_c.data(), 3);
+    p.min_depth = min_depth;
+    p.use_drag_term = use_drag_term ? 1 : 0;
+    p.use_partial_update = use_partial_update ? 1 : 0;
+    p.use_keyframe_reset = use_keyframe_reset ? 1 : 0;
+    p.keyframe_overlap_threshold = keyframe_overlap_threshold;
+    start(p);
+  }
 
   void load(const std::string& param_file) {                              // vi_ekf.cpp:101-155
     release();
     viekf_params p;
     if (!check(viekf_params_load_yaml(param_file.c_str(), &p), "load")) return;
-    params_ = p;
-    if (!check(viekf_batch_create(1, num_features_, &p, device_, &core_), "create")) return;
-    if (!check(viekf_seq_create(core_, 250, 200, &seq_), "seq_create")) return;   // LEN_STATE_HIST / LEN_MEAS_HIST, :50-51
-    nx_ = 17 + 5 * num_features_;
-    n_ = 16 + 3 * num_features_;
-    ok_ = true;
+    start(p);
   }
   bool ok() const { return ok_; }
   int max_x() const { return nx_; }
@@ -216,13 +262,13 @@ class VIEKF {
     if (k32.empty()) k32.push_back(-1);
     check(viekf_seq_drop_features(seq_, k32.data(), (int32_t)k32.size()), "clear_feature");
   }
-  int global_to_local_feature_id(const int global_id) {                   // vi_ekf_helper.cpp:114-125
+  int global_to_local_feature_id(const int global_id) const {             // vi_ekf_helper.cpp:114-125
     const std::vector<int>& tr = tracked_features();
     for (size_t i = 0; i < tr.size(); i++)
       if (tr[i] == global_id) return (int)i;
     return -1;
   }
-  const std::vector<int>& tracked_features() {                            // :272
+  const std::vector<int>& tracked_features() const {                      // :272
     std::vector<int32_t> ids((size_t)num_features_, -1);
     int32_t len = 0;
     tracked_.clear();
@@ -237,22 +283,20 @@ class VIEKF {
     if (!check(viekf_seq_keyframe_reset(seq_, nullptr, nullptr), "keyframe_reset")) return;
     if (keyframe_reset_callback_) keyframe_reset_callback_();             // :154-156
   }
-  template <class X, class = decltype(std::declval<const X&>().data())>
-  void keyframe_reset(const X& xm, Vec& xp, Mat& N) {                     // :6-12 (test hook: the filter itself is left alone)
-    xp = Vec(nx_); N = Mat(n_, n_);
-    if (ok_) check(viekf_batch_eval_reset_jacobian(core_, xm.data(), xp.data(), N.data(), VIEKF_HOST), "keyframe_reset(xm, xp, N)");
+  template <class X, class OX, class ON, class = decltype(std::declval<const X&>().data())>
+  void keyframe_reset(const X& xm, OX& xp, ON& N) {                       // :6-12 (test hook: the filter itself is left alone)
+    if (fits(xp, nx_, 1, "keyframe_reset") && fits(N, n_, n_, "keyframe_reset"))
+      check(viekf_batch_eval_reset_jacobian(core_, xm.data(), xp.data(), N.data(), VIEKF_HOST), "keyframe_reset(xm, xp, N)");
   }
   void register_keyframe_reset_callback(std::function<void(void)> cb) { keyframe_reset_callback_ = cb; }   // :325
 
   // ---- getters and setters -----------------------------------------------------------------------------------------------
-  const Vec& get_state() {                                                // :281
-    x_ = Vec(nx_);
-    if (ok_) check(viekf_batch_get_state(core_, x_.data(), nullptr, nullptr, VIEKF_HOST), "get_state");
+  const xVector& get_state() {                                            // :281 (the caller's xVector under VIEKF_SHIM_TYPES)
+    if (fits(x_, nx_, 1, "get_state")) check(viekf_batch_get_state(core_, x_.data(), nullptr, nullptr, VIEKF_HOST), "get_state");
     return x_;
   }
-  const Mat& get_covariance() {                                           // :282 (MAX_DX x MAX_DX)
-    P_ = Mat(n_, n_);
-    if (ok_) check(viekf_batch_get_state(core_, nullptr, P_.data(), nullptr, VIEKF_HOST), "get_covariance");
+  const dxMatrix& get_covariance() {                                      // :282 (MAX_DX x MAX_DX)
+    if (fits(P_, n_, n_, "get_covariance")) check(viekf_batch_get_state(core_, nullptr, P_.data(), nullptr, VIEKF_HOST), "get_covariance");
     return P_;
   }
   Vec get_covariance_diagonal() {                                         // :283
@@ -316,38 +360,48 @@ class VIEKF {
   bool BlowingUp() { return (status() & VIEKF_FLAG_BLOWING_UP) != 0; }
   bool NegativeDepth() { return (status() & VIEKF_FLAG_NEGATIVE_DEPTH) != 0; }
 
-  // ---- the reference's public test hooks, evaluated on the device --------------------------------------------------------
-  template <class X, class D, class = decltype(std::declval<const X&>().data()), class = decltype(std::declval<const D&>().data())>
-  void boxplus(const X& x, const D& dx, Vec& out) {                       // :299, vi_ekf_helper.cpp:88-98
-    out = Vec(nx_);
-    if (ok_) check(viekf_batch_boxplus(core_, x.data(), dx.data(), out.data(), VIEKF_HOST), "boxplus");
+  // ---- the reference's public test hooks, evaluated on the device (outputs: any type with data(), see the header) ----------
+  template <class X, class D, class O, class = decltype(std::declval<const X&>().data()), class = decltype(std::declval<const D&>().data())>
+  void boxplus(const X& x, const D& dx, O& out) const {                   // :299, vi_ekf_helper.cpp:88-98
+    if (fits(out, nx_, 1, "boxplus")) check(viekf_batch_boxplus(core_, x.data(), dx.data(), out.data(), VIEKF_HOST), "boxplus");
   }
-  template <class X1, class X2, class = decltype(std::declval<const X1&>().data()), class = decltype(std::declval<const X2&>().data())>
-  void boxminus(const X1& x1, const X2& x2, Vec& out) {                   // :300, vi_ekf_helper.cpp:100-111
-    out = Vec(n_);
-    if (ok_) check(viekf_batch_boxminus(core_, x1.data(), x2.data(), out.data(), VIEKF_HOST), "boxminus");
+  template <class X1, class X2, class O, class = decltype(std::declval<const X1&>().data()), class = decltype(std::declval<const X2&>().data())>
+  void boxminus(const X1& x1, const X2& x2, O& out) const {               // :300, vi_ekf_helper.cpp:100-111
+    if (fits(out, n_, 1, "boxminus")) check(viekf_batch_boxminus(core_, x1.data(), x2.data(), out.data(), VIEKF_HOST), "boxminus");
   }
-  template <class X, class U, class = decltype(std::declval<const X&>().data()), class = decltype(std::declval<const U&>().data())>
-  void dynamics(const X& x, const U& u, Vec& xdot, Mat& dfdx, Mat& dfdu) {   // :303, vi_ekf_dyn.cpp:5-11
-    xdot = Vec(n_); dfdx = Mat(n_, n_); dfdu = Mat(n_, 6);
-    if (ok_) check(viekf_batch_eval_jacobians(core_, x.data(), u.data(), xdot.data(), dfdx.data(), dfdu.data(), VIEKF_HOST), "dynamics");
+  template <class X, class U, class OX, class OA, class OG, class = decltype(std::declval<const X&>().data()),
+            class = decltype(std::declval<const U&>().data())>
+  void dynamics(const X& x, const U& u, OX& xdot, OA& dfdx, OG& dfdu) {   // :303, vi_ekf_dyn.cpp:5-11
+    if (fits(xdot, n_, 1, "dynamics") && fits(dfdx, n_, n_, "dynamics") && fits(dfdu, n_, 6, "dynamics"))
+      check(viekf_batch_eval_jacobians(core_, x.data(), u.data(), xdot.data(), dfdx.data(), dfdu.data(), VIEKF_HOST), "dynamics");
   }
-  // h_<type>(x, h, H, id): h gets 4 entries (zVector), H is the 3 x MAX_DX hMatrix (:310-318, vi_ekf_meas.cpp:281-386)
-  template <class X, class = decltype(std::declval<const X&>().data())>
-  void h(measurement_type_t type, const X& x, Vec& hv, Mat& H, const int id) {
-    hv = Vec(4); H = Mat(3, n_);
+  // h_<type>(x, h, H, id): h is the 4-entry zVector, H the 3 x MAX_DX hMatrix (:310-318, vi_ekf_meas.cpp:281-386).  The feature
+  // models take the GLOBAL feature id and look its slot up (vi_ekf_meas.cpp:346,356,371,381); an id that is not tracked evaluates
+  // to NaN (the reference indexes with -1 there).
+  template <class X, class ZV, class HM, class = decltype(std::declval<const X&>().data())>
+  void h(measurement_type_t type, const X& x, ZV& hv, HM& H, const int id) const {
+    if (!fits(hv, 4, 1, "h") || !fits(H, 3, n_, "h")) return;
     int32_t slot = id;
-    if (ok_) check(viekf_batch_eval_h_jacobian(core_, x.data(), (int32_t)type, &slot, hv.data(), H.data(), VIEKF_HOST), "h");
+    if (type == QZETA || type == FEAT || type == DEPTH || type == INV_DEPTH) {
+      slot = global_to_local_feature_id(id);
+      if (slot < 0) {
+        for (int i = 0; i < 4; i++) hv.data()[i] = NAN;
+        for (long i = 0; i < 3L * n_; i++) H.data()[i] = NAN;
+        return;
+      }
+    }
+    check(viekf_batch_eval_h_jacobian(core_, x.data(), (int32_t)type, &slot, hv.data(), H.data(), VIEKF_HOST), "h");
   }
-  template <class X> void h_acc(const X& x, Vec& hv, Mat& H, const int id) { h(ACC, x, hv, H, id); }
-  template <class X> void h_alt(const X& x, Vec& hv, Mat& H, const int id) { h(ALT, x, hv, H, id); }
-  template <class X> void h_att(const X& x, Vec& hv, Mat& H, const int id) { h(ATT, x, hv, H, id); }
-  template <class X> void h_pos(const X& x, Vec& hv, Mat& H, const int id) { h(POS, x, hv, H, id); }
-  template <class X> void h_vel(const X& x, Vec& hv, Mat& H, const int id) { h(VEL, x, hv, H, id); }
-  template <class X> void h_qzeta(const X& x, Vec& hv, Mat& H, const int id) { h(QZETA, x, hv, H, id); }
-  template <class X> void h_feat(const X& x, Vec& hv, Mat& H, const int id) { h(FEAT, x, hv, H, id); }
-  template <class X> void h_depth(const X& x, Vec& hv, Mat& H, const int id) { h(DEPTH, x, hv, H, id); }
-  template <class X> void h_inv_depth(const X& x, Vec& hv, Mat& H, const int id) { h(INV_DEPTH, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_acc(const X& x, ZV& hv, HM& H, const int id) const { h(ACC, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_alt(const X& x, ZV& hv, HM& H, const int id) const { h(ALT, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_att(const X& x, ZV& hv, HM& H, const int id) const { h(ATT, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_pos(const X& x, ZV& hv, HM& H, const int id) const { h(POS, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_vel(const X& x, ZV& hv, HM& H, const int id) const { h(VEL, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_qzeta(const X& x, ZV& hv, HM& H, const int id) const { h(QZETA, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_feat(const X& x, ZV& hv, HM& H, const int id) const { h(FEAT, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_depth(const X& x, ZV& hv, HM& H, const int id) const { h(DEPTH, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_inv_depth(const X& x, ZV& hv, HM& H, const int id) const { h(INV_DEPTH, x, hv, H, id); }
+  template <class X, class ZV, class HM> void h_pixel_vel(const X&, ZV&, HM&, const int) const {}   // :319, vi_ekf_meas.cpp:388-395: "TODO"
 
   // ---- logger ------------------------------------------------------------------------------------------------------------
   void init_logger(std::string root_filename, std::string prefix = "") {  // vi_ekf_log.cpp:79-117
@@ -357,7 +411,41 @@ class VIEKF {
   template <class T> void log_global_position(const T&) {}                // :334: LOG_GLOBAL is never opened (vi_ekf_log.cpp:85-97)
 
  private:
-  bool check(int rc, const char* what) {
+  void start(const viekf_params& p) {                                     // the filter + its sequencer from a parameter set
+    params_ = p;
+    if (!check(viekf_batch_create(1, num_features_, &p, device_, &core_), "create")) return;
+    if (!check(viekf_seq_create(core_, 250, 200, &seq_), "seq_create")) return;   // LEN_STATE_HIST / LEN_MEAS_HIST, :50-51
+    nx_ = 17 + 5 * num_features_;
+    n_ = 16 + 3 * num_features_;
+    ok_ = true;
+  }
+  void fill_table() {                                                     // vi_ekf.cpp:47-61
+    measurement_functions.assign(TOTAL_MEAS, nullptr);
+    measurement_functions[ACC] = &VIEKF::h_acc;
+    measurement_functions[ALT] = &VIEKF::h_alt;
+    measurement_functions[ATT] = &VIEKF::h_att;
+    measurement_functions[POS] = &VIEKF::h_pos;
+    measurement_functions[VEL] = &VIEKF::h_vel;
+    measurement_functions[QZETA] = &VIEKF::h_qzeta;
+    measurement_functions[FEAT] = &VIEKF::h_feat;
+    measurement_functions[DEPTH] = &VIEKF::h_depth;
+    measurement_functions[INV_DEPTH] = &VIEKF::h_inv_depth;
+    measurement_functions[PIXEL_VEL] = &VIEKF::h_pixel_vel;
+  }
+  void take(VIEKF& o) {
+    num_features_ = o.num_features_; device_ = o.device_; nx_ = o.nx_; n_ = o.n_; ok_ = o.ok_; params_ = o.params_;
+    core_ = o.core_; seq_ = o.seq_; keyframe_reset_callback_ = std::move(o.keyframe_reset_callback_);
+    o.core_ = nullptr; o.seq_ = nullptr; o.ok_ = false;
+  }
+  template <class O> bool fits(O& out, int rows, int cols, const char* what) const {
+    if (!ok_) return false;
+    shim::size_to(out, rows, cols, 0);
+    if ((long)out.size() == (long)rows * cols) return true;
+    std::cerr << "VIEKF::" << what << ": an output argument holds " << out.size() << " coefficients, " << (long)rows * cols << " needed\n";
+    ok_ = false;
+    return false;
+  }
+  bool check(int rc, const char* what) const {
     if (rc == VIEKF_OK) return true;
     std::cerr << "VIEKF::" << what << ": " << viekf_last_error() << " (" << rc << ")\n";   // diagnostics to cerr, as the reference
     ok_ = false;
@@ -390,13 +478,13 @@ class VIEKF {
   }
 
   int num_features_ = NUM_FEATURES, device_ = 0, nx_ = 0, n_ = 0;
-  bool ok_ = false;
+  mutable bool ok_ = false;
   viekf_params params_ = viekf_params();
   viekf_batch* core_ = nullptr;
   viekf_seq* seq_ = nullptr;
-  Vec x_;
-  Mat P_;
-  std::vector<int> tracked_;
+  xVector x_;
+  dxMatrix P_;
+  mutable std::vector<int> tracked_;
   std::function<void(void)> keyframe_reset_callback_;
 };
 

@@ -80,6 +80,51 @@ static void shared_clock(const char* yaml, double delay, int state_hist, int mea
   CHECK(viekf_batch_destroy(core));
 }
 
+// A ring that wraps past the start of a fused replay while steps of that replay are still unmaterialised, then a second, slower
+// sensor stamped INSIDE the replayed span: the reference's ring still holds x_ / P_ of that step (vi_ekf_meas.cpp:46-57).
+// Frames every 8 steps stamped 30 ms back (a fused replay of 8 steps per frame), ring of `state_hist` slots, an altimeter reading
+// `late_steps` steps after each frame stamped `back` steps + 2 ms before its arrival.  The stub poisons what a fused replay skips,
+// so a rewind that lands on a skipped slot, or on a newer state, shows up in the propagated time.
+static void late_second_sensor(const char* yaml, int state_hist, int late_steps, int back) {
+  viekf_params p;
+  CHECK(viekf_params_load_yaml(yaml, &p));
+  const int B = 3, N = 4, nx = 17 + 5 * N;
+  viekf_batch* core; viekf_seq* s;
+  CHECK(viekf_batch_create(B, N, &p, 0, &core));
+  CHECK(viekf_seq_create(core, state_hist, 100000, &s));   // (no queue trim here: an entry that disappears was erased)
+  std::vector<double> u((size_t)B * 6, 0.0), z((size_t)B * N * 2, 100.0), R = {10.0, 0.0, 0.0, 10.0}, za((size_t)B, 2.0), Ra = {0.01};
+  std::vector<int32_t> ids((size_t)B * N);
+  for (int b = 0; b < B; b++) for (int i = 0; i < N; i++) ids[(size_t)b * N + i] = i;
+  const double dt = 0.004;
+  double t_end = 0.0;
+  int handled_late = 0;
+  for (int k = 0; k < 200; k++) {
+    const double t = dt * k;
+    for (auto& v : u) v = urand();
+    CHECK(viekf_seq_propagate(s, u.data(), t));
+    t_end = t;
+    if (k % 8 == 3) {
+      CHECK(viekf_seq_add_frame(s, t - 0.03, nullptr, N, z.data(), R.data(), 1, ids.data(), nullptr, nullptr, nullptr));
+      CHECK(viekf_seq_handle_measurements(s, nullptr, 0, nullptr));
+    }
+    if (k > 16 && k % 8 == (3 + late_steps) % 8) {
+      int32_t q0, q1;
+      CHECK(viekf_seq_add_measurement(s, t - dt * back + 0.002, VIEKF_ALT, za.data(), 1, Ra.data(), 1, 1, nullptr, nullptr, nullptr));
+      CHECK(viekf_seq_status(s, nullptr, nullptr, &q0, nullptr));
+      CHECK(viekf_seq_handle_measurements(s, nullptr, 0, nullptr));
+      CHECK(viekf_seq_status(s, nullptr, nullptr, &q1, nullptr));
+      handled_late += (q1 == q0);          // (still queued as handled, not erased as "older than the state history")
+    }
+  }
+  std::vector<double> x((size_t)B * nx);
+  CHECK(viekf_batch_get_state(core, x.data(), nullptr, nullptr, VIEKF_HOST));
+  for (int b = 0; b < B; b++)
+    if (!(std::fabs(x[(size_t)b * nx] - t_end) <= 1e-9)) { std::fprintf(stderr, "late sensor (H %d, +%d, -%d): filter %d propagated %.9f s, its time line spans %.9f s\n", state_hist, late_steps, back, b, x[(size_t)b * nx], t_end); std::exit(14); }
+  if (handled_late < 20) { std::fprintf(stderr, "late sensor (H %d): only %d of the late readings were fused\n", state_hist, handled_late); std::exit(15); }
+  CHECK(viekf_seq_destroy(s));
+  CHECK(viekf_batch_destroy(core));
+}
+
 static void independent_clocks(const char* yaml) {
   viekf_params p;
   CHECK(viekf_params_load_yaml(yaml, &p));
@@ -132,6 +177,11 @@ int main(int argc, char** argv) {
   shared_clock(yaml, 0.0105, 250, 200, true, tmp.c_str());
   shared_clock(yaml, 0.03, 250, 200, false, tmp.c_str());
   shared_clock(yaml, 0.03, 12, 9, false, tmp.c_str());      // a ring barely longer than the rewind, a queue shorter than a frame + extras
+  late_second_sensor(yaml, 12, 6, 10);     // the replay's start slot overwritten four steps earlier: served from the orphan buffer
+  late_second_sensor(yaml, 12, 6, 9);      //   (an even / odd number of steps from the orphan: either buffer of the ping-pong ends it)
+  late_second_sensor(yaml, 12, 5, 10);
+  late_second_sensor(yaml, 13, 6, 11);
+  late_second_sensor(yaml, 24, 2, 6);      // the start slot still in the ring: re-created from it
   independent_clocks(yaml);
   std::printf("sanitized sequencer scenarios: ok\n");
   return 0;

@@ -313,3 +313,31 @@ def test_reference_call_sites_flight_matches_restated_plumbing(tmp_path, last_k)
     resets, flags, drag_on, kfr = a[q:q + 4]
     assert int(resets) == len(o.keyframe_edges) == 2          # the explicit one and the overlap-triggered one
     assert int(flags) == 0 and drag_on == 1.0 and kfr == 1.0
+
+
+def build_jactest(tmp):
+    exe = os.path.join(str(tmp), "shim_jactest_callsites")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_jactest_callsites.cpp")] + LINK)
+    return exe
+
+
+def test_jac_test_call_expressions_compile_against_the_shim(tmp_path):
+    """test/jac_test.cpp's call expressions -- the 17-argument init(...), &VIEKF::h_* as measurement_function_ptr, the public
+    measurement_functions table, boxplus / boxminus / dynamics / keyframe_reset with the caller's own fixed-size types handed in
+    through VIEKF_SHIM_TYPES -- build warning-free (reference include/vi_ekf.h:68,251-255,263)"""
+    from vi_ekf_amd import _build
+    _build.build()
+    build_jactest(tmp_path)
+
+
+@pytest.mark.gpu
+def test_jac_test_properties_through_the_shim_on_the_device(tmp_path):
+    """the reference's only asserting test flown through the shim on the GPU with its own tolerances (test/jac_test.cpp: manifold
+    1e-8, dfdx / dfdu 1e-2 and 5e-1, h_test 1e-3 (FEAT 1e-1), KF reset 1e-3 / 1e-1), fixed seeds, three fixtures per property"""
+    exe = build_jactest(tmp_path)
+    out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-3000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    for name in ("manifold", "dfdx_test", "dfdu_test", "h_test", "KF_reset_test"):
+        assert "VI_EKF.%s: OK" % name in out.stdout

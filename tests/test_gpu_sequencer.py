@@ -16,7 +16,7 @@ def _params(seed, identity_qbu=False):
 
 
 def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=64, log_root=None, log_filter=0, frames=False,
-         want_gated=True, late_alt=None):
+         want_gated=True, late_alt=None, late_at=5):
     """frames=True: every camera frame goes in through ONE viekf_seq_add_frame call (one queue entry per frame) instead of one
     add_measurement per feature; want_gated=False: handle_measurements() without the optional list (nothing waited for)"""
     import vi_ekf_amd as v
@@ -62,7 +62,7 @@ def _run(B, N, seed, delay, identity_qbu=False, nan_filter=None, steps=60, hist=
                 if want_gated:
                     gated_g[b] += gg[b]
                 gated_o[b] += os_[b].handle_measurements()
-        if late_alt is not None and k % 7 == 5 and k > 7:   # a second, slower sensor: its reading is stamped INSIDE the span the
+        if late_alt is not None and k % 7 == late_at and k > 7:   # a second, slower sensor: its reading is stamped INSIDE the span the
             tz = t - late_alt                                # last frame's replay covered
             alt = rng.normal(2.0, 0.05, (B, 1))
             sg.add_measurement(tz, alt, orc.ALT, np.array([[0.01]]), True)
@@ -106,6 +106,26 @@ def test_rewind_into_a_fused_replay(delay, late):
     assert gg == go
     st = sg.status()
     assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hist,late_at,late", [(12, 2, 0.038), (12, 2, 0.034), (12, 1, 0.038), (13, 2, 0.042), (11, 2, 0.030)])
+def test_rewind_into_a_fused_replay_whose_start_left_the_ring(hist, late_at, late):
+    """a ring that wraps past the slot a fused replay started from while steps of that replay are still unmaterialised,
+    then a slower sensor stamped inside the span.  The reference's ring still holds x_ / P_ of that step (vi_ekf_meas.cpp:46-57) and
+    fuses the reading; the sequencer serves the rewind from the buffer it took out of the ring when the start slot was due to be
+    overwritten (viekf_seq.cpp: before_overwrite / rewind_to).  Frames every 7 steps stamped 30 ms back, ring of `hist` slots, an
+    altimeter reading 5 - 6 steps after each frame stamped `late` s back.  Against the restated plumbing, which keeps every slot."""
+    B, N = 3, 6
+    g, sg, os_, gg, go = _run(B, N, seed=13, delay=0.03, frames=True, late_alt=late, late_at=late_at, hist=hist, steps=80)
+    for b in range(B):
+        assert sg.tracked_features()[b] == list(os_[b].f.feature_ids)
+        assert not [m for m in os_[b].log if "state buffer" in m], os_[b].log      # (the reference does fuse these readings)
+    assert_close(g.get_state(), np.stack([o.f.x for o in os_]), "x")
+    assert_close(g.get_covariance(), np.stack([o.f.P for o in os_]), "P")
+    st = sg.status()
+    assert st["ring_index"] == os_[0].i and abs(st["t"] - os_[0].t[os_[0].i]) < 1e-12
+    assert st["queued"] == len(os_[0].zbuf) and st["inputs"] == len(os_[0].u)
 
 
 @pytest.mark.gpu

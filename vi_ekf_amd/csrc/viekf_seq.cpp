@@ -128,6 +128,17 @@ struct viekf_seq {
   std::vector<double> t;                                           // t_ ring
   std::vector<uint8_t> mat;                                        // ring slot holds its state (0: a step inside a fused replay --
                                                                    // its time is known, its state is re-created on demand)
+  // Shared clock: ring slot -> buffer of the core's history ring.  The core holds H + 1 buffers; the one outside the ring (`extra`)
+  // is free or holds the ORPHAN: the state a fused replay started from, taken out of the ring (a swap of two indices, no copy) at
+  // the moment its slot was due to be overwritten while steps of that replay were still unmaterialised -- the reference's ring
+  // still has x_ / P_ for those steps (vi_ekf_meas.cpp:46-57), so a late measurement may rewind to one of them.
+  std::vector<int> phys;
+  int extra = 0;
+  bool orph = false;
+  double orph_t = NAN;
+  struct Step { int slot; double t; std::vector<double> u; };
+  std::vector<Step> orph_steps;                                    // the orphan's unmaterialised steps, oldest first
+  std::vector<std::vector<double>> slot_u;                         // per ring slot: the (rotated) input [B][6] its step was made with
   int i = 0;                                                       // i_
   double start_t = NAN;
   std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [B][6]), newest first
@@ -221,6 +232,19 @@ std::string eigen_row(const double* v, int n) {
   return r;
 }
 
+// Ring slot `ip` (the oldest state of the ring) is about to be overwritten.  If it is the slot a fused replay started from and the
+// replay's next step is still unmaterialised, its buffer leaves the ring as the orphan (with the list of those steps and their
+// inputs) and the slot gets the buffer that was outside: a later rewind into the span can still be served (rewind_to).
+void before_overwrite(viekf_seq* s, int ip) {
+  const int nxt = (ip + 1) % s->H;
+  if (!s->mat[ip] || s->mat[nxt]) return;
+  s->orph_steps.clear();
+  for (int q = nxt; !s->mat[q] && q != ip; q = (q + 1) % s->H) s->orph_steps.push_back({q, s->t[q], s->slot_u[q]});
+  s->orph = true;
+  s->orph_t = s->t[ip];
+  std::swap(s->extra, s->phys[ip]);
+}
+
 // numeric core of propagate_state (vi_ekf.cpp:291-311) with ring bookkeeping; `u` is what the caller hands to
 // propagate_state (the batch rotates it by q_b_u itself, :265-267)
 int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
@@ -249,7 +273,8 @@ int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
     if (int rc = viekf_batch_eval_xdot(s->core, u, xdot.data(), VIEKF_HOST)) return rc;
   }
   const int ip = (s->i + 1) % s->H;                                // :298: x_[ip], P_[ip] are written from x_[i_], P_[i_] --
-  if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), ip, VIEKF_HOST)) return rc;   // the old slot stays as history
+  before_overwrite(s, ip);
+  if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), s->phys[ip], VIEKF_HOST)) return rc;   // the old slot stays as history
   s->i = ip;                                                       // :306
   s->t[s->i] = t;
   s->mat[s->i] = 1;
@@ -285,16 +310,20 @@ int replay_inputs(viekf_seq* s, size_t from) {
     }
     std::vector<double> U((size_t)K * B * 6), DT((size_t)K * B);
     std::vector<int32_t> slots(K);
+    std::vector<int32_t> pslots(K);
     for (int k = 0; k < K; k++) {
       std::memcpy(U.data() + (size_t)k * B * 6, s->u[idx[done + k]].second.data(), sizeof(double) * 6 * (size_t)B);
       std::fill(DT.begin() + (size_t)k * B, DT.begin() + (size_t)(k + 1) * B, dtv[done + k]);
       slots[k] = (s->i + 1 + k) % s->H;
+      before_overwrite(s, slots[k]);
+      pslots[k] = s->phys[slots[k]];
     }
     int32_t written = 1;
-    if (int rc = viekf_batch_propagate_n_to(s->core, K, U.data(), DT.data(), slots.data(), &written, VIEKF_HOST)) return rc;
+    if (int rc = viekf_batch_propagate_n_to(s->core, K, U.data(), DT.data(), pslots.data(), &written, VIEKF_HOST)) return rc;
     for (int k = 0; k < K; k++) {
       s->t[slots[k]] = s->u[idx[done + k]].first;
       s->mat[slots[k]] = (written || k == K - 1) ? 1 : 0;
+      if (!s->mat[slots[k]]) s->slot_u[slots[k]] = s->u[idx[done + k]].second;   // (what re-creating this step later needs)
     }
     s->i = slots[K - 1];
     done += (size_t)K;
@@ -302,26 +331,70 @@ int replay_inputs(viekf_seq* s, size_t from) {
   return VIEKF_OK;
 }
 
-// makes ring slot `target` the live state (the rewind, vi_ekf_meas.cpp:50-52); a slot inside a fused replay is first re-created:
-// back to the nearest slot that holds its state, then forward step by step with the inputs those steps were made with
-int rewind_to(viekf_seq* s, int target) {
+// makes ring slot `target` the live state (the rewind, vi_ekf_meas.cpp:50-52).  A slot inside a fused replay is first re-created:
+// from the nearest older slot that holds its state, forward step by step with the inputs those steps were made with -- or, when that
+// slot has been overwritten since (the ring wrapped past it), from the orphan buffer that left the ring then (before_overwrite).
+// *found = false: the state cannot be re-created (not reached with the bookkeeping above; the caller then treats the measurement
+// as older than the state history, vi_ekf_meas.cpp:59-64, instead of failing on it for ever).
+int rewind_to(viekf_seq* s, int target, bool* found) {
+  const int H = s->H, B = s->B;
+  *found = true;
+  if (s->mat[target]) {
+    if (target != s->i) {
+      if (int rc = viekf_batch_select(s->core, s->phys[target])) return rc;
+      s->i = target;
+    }
+    return VIEKF_OK;
+  }
   int jv = target, back = 0;
-  while (!s->mat[jv] && back < s->H) { jv = (jv + s->H - 1) % s->H; back++; }
-  if (!s->mat[jv]) return VIEKF_ERR_INVALID;
-  if (jv != s->i) {
-    if (int rc = viekf_batch_select(s->core, jv)) return rc;
-    s->i = jv;
+  do { jv = (jv + H - 1) % H; back++; } while (!s->mat[jv] && back < H);
+  if (s->mat[jv] && s->t[jv] < s->t[target]) {                     // (an overwritten start shows up as a NEWER state here)
+    if (jv != s->i) {
+      if (int rc = viekf_batch_select(s->core, s->phys[jv])) return rc;
+      s->i = jv;
+    }
+    for (int q = 1; q <= back; q++) {
+      const int slot = (jv + q) % H;
+      if (s->slot_u[slot].size() != (size_t)B * 6) return VIEKF_ERR_INVALID;
+      const std::vector<double> uq = s->slot_u[slot];              // (a copy: propagate_core may not touch slot_u, but stay safe)
+      if (int rc = propagate_core(s, uq.data(), s->t[slot], false)) return rc;   // writes slot (i + 1) % H = `slot`, marks it
+      if (s->i != slot) return VIEKF_ERR_INVALID;
+    }
+    return VIEKF_OK;
   }
-  for (int q = 1; q <= back; q++) {
-    const int slot = (jv + q) % s->H;
-    const double tq = s->t[slot];
-    const std::vector<double>* uq = nullptr;
-    for (const auto& e : s->u)
-      if (e.first == tq) { uq = &e.second; break; }
-    if (!uq) return VIEKF_ERR_INVALID;                            // (inputs and ring have the same depth: the step's input is there)
-    if (int rc = propagate_core(s, uq->data(), tq, false)) return rc;   // writes slot (i + 1) % H = `slot`, marks it
-    if (s->i != slot) return VIEKF_ERR_INVALID;
+  // the orphan: steps [0, idx] of its list lead to the target
+  int idx = -1;
+  if (s->orph)
+    for (size_t k = 0; k < s->orph_steps.size(); k++)
+      if (s->orph_steps[k].slot == target && s->orph_steps[k].t == s->t[target]) { idx = (int)k; break; }
+  if (idx < 0) { *found = false; return VIEKF_OK; }
+  // ping-pong between the target's buffer and a second free one: another still unmaterialised step's, or the orphan buffer itself
+  // once it has been read (nothing else can need it then: no other step of its replay is left in the ring)
+  int owner = -1;
+  for (size_t k = 0; k < s->orph_steps.size() && owner < 0; k++) {
+    const auto& st = s->orph_steps[k];
+    if ((int)k != idx && !s->mat[st.slot] && s->t[st.slot] == st.t) owner = st.slot;
   }
+  const int bufA = s->phys[target], bufB = owner >= 0 ? s->phys[owner] : s->extra;
+  if (int rc = viekf_batch_select(s->core, s->extra)) return rc;
+  double tprev = s->orph_t;
+  std::vector<double> dts((size_t)B);
+  int last = bufA;
+  for (int k = 0; k <= idx; k++) {
+    const auto& st = s->orph_steps[(size_t)k];
+    if (st.u.size() != (size_t)B * 6) return VIEKF_ERR_INVALID;
+    std::fill(dts.begin(), dts.end(), st.t - tprev);
+    last = (k % 2 == 0) ? bufA : bufB;
+    if (int rc = viekf_batch_propagate_to(s->core, st.u.data(), dts.data(), last, VIEKF_HOST)) return rc;
+    tprev = st.t;
+  }
+  if (owner < 0 && idx >= 1) s->orph = false;                      // (the orphan buffer was written by step 1)
+  if (last != bufA) {                                              // the state ended in the other buffer: the two trade places
+    if (owner >= 0) std::swap(s->phys[target], s->phys[owner]);
+    else std::swap(s->phys[target], s->extra);
+  }
+  s->mat[target] = 1;
+  s->i = target;
   return VIEKF_OK;
 }
 
@@ -658,12 +731,16 @@ int viekf_seq_create(viekf_batch* core, int32_t state_hist, int32_t meas_hist, v
   int32_t B, N, nx, n;
   if (int rc = viekf_batch_dims(core, &B, &N, &nx, &n)) { delete s; return rc; }
   if (int rc = viekf_batch_get_params(core, &s->prm)) { delete s; return rc; }
-  if (int rc = viekf_batch_history_resize(core, state_hist)) { delete s; return rc; }
+  if (int rc = viekf_batch_history_resize(core, state_hist + 1)) { delete s; return rc; }   // (+ 1: the buffer outside the ring)
   if (int rc = viekf_batch_snapshot(core, 0)) { delete s; return rc; }     // the live state moves into ring slot i_ = 0
   if (int rc = viekf_batch_select(core, 0)) { delete s; return rc; }
   s->B = B; s->N = N; s->H = state_hist; s->MH = meas_hist;
   s->t.assign(state_hist, NAN);                                    // vi_ekf.cpp:22-27
   s->mat.assign(state_hist, 1);
+  s->phys.resize(state_hist);
+  for (int k = 0; k < state_hist; k++) s->phys[k] = k;
+  s->extra = state_hist;
+  s->slot_u.assign(state_hist, {});
   s->ids.assign(B, {});
   s->slot_of.assign(B, {});
   s->next_id.assign(B, 0);
@@ -1025,8 +1102,14 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     s->zbuf.erase(s->zbuf.begin() + zi);
     return finish();
   }
-  if (target != s->i)     // rewind = the ring slot becomes the live state (:50-52); feature counts are not part of the ring
-    if (int rc = rewind_to(s, target)) return rc;
+  if (target != s->i) {   // rewind = the ring slot becomes the live state (:50-52); feature counts are not part of the ring
+    bool found = true;
+    if (int rc = rewind_to(s, target, &found)) return rc;
+    if (!found) {                                                  // as :59-64: no state to go back to -- the measurement is dropped
+      s->zbuf.erase(s->zbuf.begin() + zi);
+      return finish();
+    }
+  }
   std::vector<int32_t> res;
   size_t tail = 0;
   ui--;                                                            // :74
@@ -1082,10 +1165,27 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
     if (!left_inner_by_break) break;   // (the inner condition can only fail with ui == 0)
   }
   if (int rc = replay_inputs(s, tail)) return rc;                  // ... and u[0] (:118), fused into one launch where possible
-  {   // :121-122 (the reference counts measurements: a frame block weighs its `count`)
+  {   // :121-122: single measurements leave from the old end until LEN_MEAS_HIST are left; a frame block weighs its `count` and
+      // gives up only as many of its members as the reference would pop -- the ones it consumes first sit at the very end
     long total = 0;
     for (const auto& e : s->zbuf) total += e.count;
-    while (total > s->MH && !s->zbuf.empty()) { total -= s->zbuf.back().count; s->zbuf.pop_back(); }
+    while (total > s->MH && !s->zbuf.empty()) {
+      SeqMeas& e = s->zbuf.back();
+      const long drop = total - s->MH;
+      if (drop >= e.count) { total -= e.count; s->zbuf.pop_back(); continue; }
+      const int keep = e.count - (int)drop;
+      std::vector<double> z((size_t)B * keep * 2);
+      std::vector<int32_t> id((size_t)B * keep);
+      std::vector<uint8_t> pr((size_t)B * keep);
+      for (int b = 0; b < B; b++)
+        for (int j = 0; j < keep; j++) {
+          const size_t o = (size_t)b * keep + j, f = (size_t)b * e.count + drop + j;
+          z[2 * o] = e.z[2 * f]; z[2 * o + 1] = e.z[2 * f + 1]; id[o] = e.id[f]; pr[o] = e.present[f];
+        }
+      e.z.swap(z); e.id.swap(id); e.present.swap(pr);
+      e.count = keep;
+      total -= drop;
+    }
   }
   while ((int)s->u.size() > s->H) s->u.pop_back();                 // :125-126
   return finish();
