@@ -247,6 +247,16 @@ int viekf_batch_restore_filters(viekf_batch *b, const int32_t *slot, viekf_mem w
  *  handed to snapshot_filters / restore_filters in DEVICE memory cannot be checked by the host: an out-of-range one is skipped
  *  and that filter's VIEKF_FLAG_INTERNAL is raised.) */
 int viekf_batch_propagate_to(viekf_batch *b, const double *u, const double *dt, int32_t dst_slot, viekf_mem where);
+/* The zero-copy ring for filters on independent clocks: x_[i_], P_[i_] of EVERY filter are a slot of its own
+ * (include/vi_ekf.h:156-160, one reference object per filter).  select_filters: slot [batch] in HOST memory, filter b's live state
+ * becomes ring slot slot[b] without a copy (< 0: unchanged; the first call names a slot for every filter and needs the live state
+ * in the batch's own buffers -- viekf_batch_snapshot_filters puts it into the ring first); every later call (updates, getters,
+ * feature changes ...) works on each filter's own slot.  propagate_filters_to: the filters with dst_slot[b] >= 0 step from their
+ * live slot INTO dst_slot[b], which becomes their live slot (src/vi_ekf/vi_ekf.cpp:298-306 per filter: the fused kernel loads
+ * filter b from slot i_b and stores it into slot i_b + 1, no pass over P besides the step's own); the others are not touched.
+ * dst_slot is HOST memory, u / dt as `where` says.  viekf_batch_history_resize(b, 0) brings every live state home again. */
+int viekf_batch_select_filters(viekf_batch *b, const int32_t *slot);
+int viekf_batch_propagate_filters_to(viekf_batch *b, const double *u, const double *dt, const int32_t *dst_slot, viekf_mem where);
 /* K propagates in a row, step k into ring slot dst_slots[k] (all different, none of them the live slot); the last one becomes the
  * live state.  u [K][batch][6], dt [K][batch], 1 <= K <= 64.  This is the replay after a rewind (src/vi_ekf/vi_ekf_meas.cpp:106-118:
  * propagate_state(u, t, false) for every stored input).  Where the fused kernel applies it is ONE launch and only the LAST slot is
@@ -298,7 +308,7 @@ int viekf_seq_create(viekf_batch *core, int32_t state_hist, int32_t meas_hist, v
  * stamps, different camera delays) and still share the batch.  Every filter keeps its own time ring, input queue and measurement
  * queue and makes its own handle_measurements decisions (deferral, rewind target, replay length: src/vi_ekf/vi_ekf_meas.cpp:6-127
  * per filter); the device steps of a call are batched over the filters that take the same kind of step (viekf_batch_set_active,
- * viekf_batch_restore_filters / _snapshot_filters).  Each filter's results are those of a batch of one fed the same inputs.  The
+ * viekf_batch_select_filters / _propagate_filters_to: every filter's ring is zero-copy, a rewind is an index).  Each filter's results are those of a batch of one fed the same inputs.  The
  * state history is a snapshot ring here (one copy of (x, P) per propagate, not the zero-copy ring of the shared clock).
  *   viekf_seq_propagate_t / _add_measurement_t take t [batch] and an optional mask [batch] (0 = this filter has no sample in
  *   this call); viekf_seq_propagate / _add_measurement with one t still work (same stamp for everybody); everything else

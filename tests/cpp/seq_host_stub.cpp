@@ -23,6 +23,11 @@ struct viekf_batch {
   double* xs(int slot) { return slot < 0 ? x.data() : rx[(size_t)slot].data(); }
   double* Ps(int slot) { return slot < 0 ? P.data() : rP[(size_t)slot].data(); }
   bool on(int b) const { return !active_on || active[(size_t)b]; }
+  // per-filter live ring slots (viekf_batch_select_filters): filter i's live state is slot lf[i]
+  bool per_filter = false;
+  std::vector<int> lf;
+  double* xf(int i) { return xs(per_filter ? lf[(size_t)i] : live) + (size_t)i * nx; }
+  double* Pf(int i) { return Ps(per_filter ? lf[(size_t)i] : live) + (size_t)i * n * n; }
 };
 
 extern "C" {
@@ -43,6 +48,11 @@ int viekf_batch_dims(const viekf_batch* b, int32_t* batch, int32_t* nf, int32_t*
 int viekf_batch_get_params(const viekf_batch* b, viekf_params* out) { *out = b->p; return VIEKF_OK; }
 int viekf_batch_set_async(viekf_batch*, int32_t) { return VIEKF_OK; }
 int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
+  if (b->per_filter) {
+    std::vector<double> x(b->x.size()), P(b->P.size());
+    for (int i = 0; i < b->B; i++) { std::memcpy(x.data() + (size_t)i * b->nx, b->xf(i), sizeof(double) * b->nx); std::memcpy(P.data() + (size_t)i * b->n * b->n, b->Pf(i), sizeof(double) * b->n * b->n); }
+    b->x = x; b->P = P; b->per_filter = false;
+  }
   if (b->live >= 0) { b->x = b->rx[(size_t)b->live]; b->P = b->rP[(size_t)b->live]; b->live = -1; }
   b->rx.assign((size_t)depth, std::vector<double>(b->x.size(), NAN));
   b->rP.assign((size_t)depth, std::vector<double>(b->P.size(), NAN));
@@ -65,10 +75,42 @@ static void prop(viekf_batch* b, int src, int dst, const double* u, const double
     if (xo != xi) std::memcpy(xo, xi, sizeof(double) * b->nx);
     if (!b->on(i)) continue;
     xo[0] += dt[i]; xo[1] += 1.0; xo[3] += u[6 * (size_t)i];
+    xo[7] = xo[7] * 1.0000001 + u[6 * (size_t)i] * dt[i] + 0.37;   // depends on the ORDER of the steps and on which input each one got
   }
   if (src != dst) std::memcpy(b->Ps(dst), b->Ps(src), sizeof(double) * b->P.size());
 }
-int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, viekf_mem) { b->calls++; prop(b, b->live, b->live, u, dt); return VIEKF_OK; }
+int viekf_batch_propagate(viekf_batch* b, const double* u, const double* dt, viekf_mem) {
+  b->calls++;
+  if (b->per_filter) {
+    for (int i = 0; i < b->B; i++) { if (!b->on(i)) continue; double* x = b->xf(i); x[0] += dt[i]; x[1] += 1.0; x[3] += u[6 * (size_t)i]; x[7] = x[7] * 1.0000001 + u[6 * (size_t)i] * dt[i] + 0.37; }
+    return VIEKF_OK;
+  }
+  prop(b, b->live, b->live, u, dt);
+  return VIEKF_OK;
+}
+int viekf_batch_select_filters(viekf_batch* b, const int32_t* slot) {
+  if (b->live >= 0 || b->rx.empty()) return VIEKF_ERR_INVALID;
+  for (int i = 0; i < b->B; i++) if (slot[i] >= (int)b->rx.size() || (slot[i] < 0 && !b->per_filter)) return VIEKF_ERR_INVALID;
+  if (!b->per_filter) { b->lf.assign((size_t)b->B, 0); b->per_filter = true; }
+  for (int i = 0; i < b->B; i++) if (slot[i] >= 0) b->lf[(size_t)i] = slot[i];
+  return VIEKF_OK;
+}
+int viekf_batch_propagate_filters_to(viekf_batch* b, const double* u, const double* dt, const int32_t* dst, viekf_mem) {
+  if (!b->per_filter) return VIEKF_ERR_INVALID;
+  for (int i = 0; i < b->B; i++) if (dst[i] >= (int)b->rx.size() || (dst[i] >= 0 && dst[i] == b->lf[(size_t)i])) return VIEKF_ERR_INVALID;
+  b->calls++;
+  for (int i = 0; i < b->B; i++) {
+    if (dst[i] < 0) continue;
+    double* xi = b->xf(i); double* Pi = b->Pf(i);
+    double* xo = b->rx[(size_t)dst[i]].data() + (size_t)i * b->nx;
+    double* Po = b->rP[(size_t)dst[i]].data() + (size_t)i * b->n * b->n;
+    std::memcpy(xo, xi, sizeof(double) * b->nx); std::memcpy(Po, Pi, sizeof(double) * b->n * b->n);
+    xo[0] += dt[i]; xo[1] += 1.0; xo[3] += u[6 * (size_t)i];
+    xo[7] = xo[7] * 1.0000001 + u[6 * (size_t)i] * dt[i] + 0.37;
+    b->lf[(size_t)i] = dst[i];
+  }
+  return VIEKF_OK;
+}
 int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, int32_t dst, viekf_mem) {
   if (dst < 0 || dst >= (int)b->rx.size() || b->active_on) return VIEKF_ERR_INVALID;
   b->calls++;
@@ -76,12 +118,19 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   b->live = dst;
   return VIEKF_OK;
 }
-// the fused form: only the LAST slot is written (the stub poisons the ones in between, as stale device memory would be wrong)
+// the fused form: only the LAST slot is written (the stub poisons the ones in between, as stale device memory would be wrong);
+// stub_write_every_slot != 0: the HBM-path family's behaviour, every slot written -- the run the fused one is compared with
+int stub_write_every_slot = 0;
 int viekf_batch_propagate_n_to(viekf_batch* b, int32_t K, const double* u, const double* dt, const int32_t* dst, int32_t* written, viekf_mem) {
   if (K < 1 || K > 64 || b->active_on) return VIEKF_ERR_INVALID;
   for (int k = 0; k < K; k++)
     if (dst[k] < 0 || dst[k] >= (int)b->rx.size() || dst[k] == b->live) return VIEKF_ERR_INVALID;
   b->calls++;
+  if (stub_write_every_slot) {
+    for (int k = 0; k < K; k++) { prop(b, b->live, dst[k], u + (size_t)6 * b->B * k, dt + (size_t)b->B * k); b->live = dst[k]; }
+    if (written) *written = 1;
+    return VIEKF_OK;
+  }
   int cur = b->live;
   for (int k = 0; k < K; k++) {
     prop(b, cur, dst[K - 1], u + (size_t)6 * b->B * k, dt + (size_t)b->B * k);
@@ -102,7 +151,7 @@ int viekf_batch_update_feat(viekf_batch* b, const double* z, const int32_t* slot
       if (sl < 0) code = -1;
       else if (sl >= b->len[(size_t)i]) code = 3;
       else if (std::isnan(z[((size_t)i * M + m) * 2])) code = 2;
-      else if (b->on(i)) b->xs(b->live)[(size_t)i * b->nx + 2] += 1.0;
+      else if (b->on(i)) { b->xf(i)[2] += 1.0; b->xf(i)[7] = b->xf(i)[7] * 0.9999 + 0.01 * z[((size_t)i * M + m) * 2]; }
       if (result) result[(size_t)i * M + m] = b->on(i) ? code : -1;
     }
   (void)R;
@@ -116,7 +165,7 @@ int viekf_batch_update(viekf_batch* b, int32_t type, const double* z, int32_t zd
     if (active && active[i] == 2) code = -1;
     else if (slot && (type == 5 || type == 6 || type == 8 || type == 9) && (slot[i] < 0 || slot[i] >= b->len[(size_t)i])) code = slot[i] < 0 ? -1 : 3;
     else if (std::isnan(z[(size_t)i * zdim])) code = 2;
-    else b->xs(b->live)[(size_t)i * b->nx + 4] += 1.0;
+    else { b->xf(i)[4] += 1.0; b->xf(i)[7] = b->xf(i)[7] * 0.999 + z[(size_t)i * zdim]; }
     if (result) result[i] = code;
   }
   return VIEKF_OK;
@@ -125,7 +174,7 @@ int viekf_batch_init_feature(viekf_batch* b, const double* pix, const double*, c
   for (int i = 0; i < b->B; i++) {
     int took = 0;
     if ((!mask || mask[i]) && b->len[(size_t)i] < b->N) {
-      b->xs(b->live)[(size_t)i * b->nx + 17 + 5 * b->len[(size_t)i]] = pix[2 * (size_t)i];
+      b->xf(i)[17 + 5 * b->len[(size_t)i]] = pix[2 * (size_t)i];
       b->len[(size_t)i]++;
       took = 1;
     }
@@ -136,7 +185,7 @@ int viekf_batch_init_feature(viekf_batch* b, const double* pix, const double*, c
 int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_len, viekf_mem) {
   for (int i = 0; i < b->B; i++) {
     int k = 0;
-    double* x = b->xs(b->live) + (size_t)i * b->nx;
+    double* x = b->xf(i);
     for (int f = 0; f < b->len[(size_t)i]; f++)
       if (keep[(size_t)i * b->N + f]) { std::memmove(x + 17 + 5 * k, x + 17 + 5 * f, sizeof(double) * 5); k++; }
     for (int f = k; f < b->N; f++) std::memset(x + 17 + 5 * f, 0, sizeof(double) * 5);
@@ -148,21 +197,25 @@ int viekf_batch_keep_features(viekf_batch* b, const uint8_t* keep, int32_t* new_
 int viekf_batch_keyframe_reset(viekf_batch* b, const uint8_t* mask, double* edge, viekf_mem) {
   for (int i = 0; i < b->B; i++) {
     if (mask && !mask[i]) continue;
-    double* x = b->xs(b->live) + (size_t)i * b->nx;
+    double* x = b->xf(i);
     if (edge) { double* e = edge + 17 * (size_t)i; std::memset(e, 0, sizeof(double) * 17); e[0] = x[0]; e[3] = 1.0; }
     x[5] += 1.0;
   }
   return VIEKF_OK;
 }
 int viekf_batch_get_state(viekf_batch* b, double* x, double* P, int32_t* len, viekf_mem) {
-  if (x) std::memcpy(x, b->xs(b->live), sizeof(double) * b->x.size());
-  if (P) std::memcpy(P, b->Ps(b->live), sizeof(double) * b->P.size());
+  for (int i = 0; i < b->B; i++) {
+    if (x) std::memcpy(x + (size_t)i * b->nx, b->xf(i), sizeof(double) * b->nx);
+    if (P) std::memcpy(P + (size_t)i * b->n * b->n, b->Pf(i), sizeof(double) * b->n * b->n);
+  }
   if (len) std::memcpy(len, b->len.data(), sizeof(int32_t) * b->B);
   return VIEKF_OK;
 }
 int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, const int32_t* len, viekf_mem) {
-  if (x) std::memcpy(b->xs(b->live), x, sizeof(double) * b->x.size());
-  if (P) std::memcpy(b->Ps(b->live), P, sizeof(double) * b->P.size());
+  for (int i = 0; i < b->B; i++) {
+    if (x) std::memcpy(b->xf(i), x + (size_t)i * b->nx, sizeof(double) * b->nx);
+    if (P) std::memcpy(b->Pf(i), P + (size_t)i * b->n * b->n, sizeof(double) * b->n * b->n);
+  }
   if (len) std::memcpy(b->len.data(), len, sizeof(int32_t) * b->B);
   return VIEKF_OK;
 }
@@ -185,9 +238,9 @@ static int ring_filters(viekf_batch* b, const int32_t* slot, int to_ring) {
     if (sl < 0) continue;
     if (sl >= (int)b->rx.size()) return VIEKF_ERR_INVALID;
     double* rx = b->rx[(size_t)sl].data() + (size_t)i * b->nx;
-    double* lx = b->x.data() + (size_t)i * b->nx;
+    double* lx = b->per_filter ? b->xf(i) : b->x.data() + (size_t)i * b->nx;
     double* rP = b->rP[(size_t)sl].data() + (size_t)i * b->n * b->n;
-    double* lP = b->P.data() + (size_t)i * b->n * b->n;
+    double* lP = b->per_filter ? b->Pf(i) : b->P.data() + (size_t)i * b->n * b->n;
     if (to_ring) { std::memcpy(rx, lx, sizeof(double) * b->nx); std::memcpy(rP, lP, sizeof(double) * b->n * b->n); }
     else { std::memcpy(lx, rx, sizeof(double) * b->nx); std::memcpy(lP, rP, sizeof(double) * b->n * b->n); }
   }

@@ -85,7 +85,23 @@ static void shared_clock(const char* yaml, double delay, int state_hist, int mea
 // Frames every 8 steps stamped 30 ms back (a fused replay of 8 steps per frame), ring of `state_hist` slots, an altimeter reading
 // `late_steps` steps after each frame stamped `back` steps + 2 ms before its arrival.  The stub poisons what a fused replay skips,
 // so a rewind that lands on a skipped slot, or on a newer state, shows up in the propagated time.
-static void late_second_sensor(const char* yaml, int state_hist, int late_steps, int back) {
+extern "C" int stub_write_every_slot;   // tests/cpp/seq_host_stub.cpp
+static std::vector<double> late_second_sensor_run(const char* yaml, int state_hist, int late_steps, int back, int period = 8, bool with_alt = false);
+// ... and the same flight with a core that writes every ring slot (nothing to re-create, no orphan): the stub's state depends on
+// the order of the steps and on the input each step got, so the two final states are equal bit for bit only if every re-created
+// state was re-created from the right start with the right inputs.
+static void late_second_sensor(const char* yaml, int state_hist, int late_steps, int back, int period = 8, bool with_alt = false) {
+  const unsigned long long seed = rng_state;
+  stub_write_every_slot = 0;
+  const std::vector<double> fused = late_second_sensor_run(yaml, state_hist, late_steps, back, period, with_alt);
+  rng_state = seed;
+  stub_write_every_slot = 1;
+  const std::vector<double> plain = late_second_sensor_run(yaml, state_hist, late_steps, back, period, with_alt);
+  stub_write_every_slot = 0;
+  for (size_t i = 0; i < fused.size(); i++)
+    if (!(fused[i] == plain[i])) { std::fprintf(stderr, "late sensor (H %d, +%d, -%d): state entry %zu differs between the fused and the every-slot core: %.17g vs %.17g\n", state_hist, late_steps, back, i, fused[i], plain[i]); std::exit(16); }
+}
+static std::vector<double> late_second_sensor_run(const char* yaml, int state_hist, int late_steps, int back, int period, bool with_alt) {
   viekf_params p;
   CHECK(viekf_params_load_yaml(yaml, &p));
   const int B = 3, N = 4, nx = 17 + 5 * N;
@@ -103,11 +119,13 @@ static void late_second_sensor(const char* yaml, int state_hist, int late_steps,
     for (auto& v : u) v = urand();
     CHECK(viekf_seq_propagate(s, u.data(), t));
     t_end = t;
-    if (k % 8 == 3) {
+    if (k % period == 3) {
       CHECK(viekf_seq_add_frame(s, t - 0.03, nullptr, N, z.data(), R.data(), 1, ids.data(), nullptr, nullptr, nullptr));
+      if (with_alt)    // (the frame's own altimeter reading 1 ms later: the fused replay then starts from ITS slot)
+        CHECK(viekf_seq_add_measurement(s, t - 0.03 + 0.001, VIEKF_ALT, za.data(), 1, Ra.data(), 1, 1, nullptr, nullptr, nullptr));
       CHECK(viekf_seq_handle_measurements(s, nullptr, 0, nullptr));
     }
-    if (k > 16 && k % 8 == (3 + late_steps) % 8) {
+    if (k > 16 && k % period == (3 + late_steps) % period) {
       int32_t q0, q1;
       CHECK(viekf_seq_add_measurement(s, t - dt * back + 0.002, VIEKF_ALT, za.data(), 1, Ra.data(), 1, 1, nullptr, nullptr, nullptr));
       CHECK(viekf_seq_status(s, nullptr, nullptr, &q0, nullptr));
@@ -123,12 +141,13 @@ static void late_second_sensor(const char* yaml, int state_hist, int late_steps,
   if (handled_late < 20) { std::fprintf(stderr, "late sensor (H %d): only %d of the late readings were fused\n", state_hist, handled_late); std::exit(15); }
   CHECK(viekf_seq_destroy(s));
   CHECK(viekf_batch_destroy(core));
+  return x;
 }
 
-static void independent_clocks(const char* yaml) {
+static void independent_clocks(const char* yaml, const int B) {   // (B >= 256: the queues are planned on several host threads)
   viekf_params p;
   CHECK(viekf_params_load_yaml(yaml, &p));
-  const int B = 6, N = 5, nx = 17 + 5 * N;
+  const int N = 5, nx = 17 + 5 * N;
   viekf_batch* core; viekf_seq* s;
   CHECK(viekf_batch_create(B, N, &p, 0, &core));
   CHECK(viekf_seq_create_independent(core, 32, 40, &s));
@@ -142,14 +161,14 @@ static void independent_clocks(const char* yaml) {
   for (int round = 0; round < 500; round++) {
     std::vector<uint8_t> mask(B, 0);
     for (int b = 0; b < B; b++) {
-      if (urand() < 0.7) { mask[b] = 1; tt[b] = origin[b] + period[b] * steps[b]; steps[b]++; last[b] = tt[b]; if (std::isnan(first[b])) first[b] = tt[b]; }
+      if (urand() < 0.7) { mask[b] = 1; tt[b] = origin[b % 6] + period[b % 6] * steps[b]; steps[b]++; last[b] = tt[b]; if (std::isnan(first[b])) first[b] = tt[b]; }
       for (int c = 0; c < 6; c++) u[(size_t)b * 6 + c] = urand();
     }
     CHECK(viekf_seq_propagate_t(s, u.data(), tt.data(), mask.data()));
     if (round % 7 == 4) {
       std::vector<double> tz(B);
       std::vector<uint8_t> m2(B, 0);
-      for (int b = 0; b < B; b++) { tz[b] = last[b] - delay[b]; m2[b] = (steps[b] > 2 && urand() < 0.8) ? 1 : 0; }
+      for (int b = 0; b < B; b++) { tz[b] = last[b] - delay[b % 6]; m2[b] = (steps[b] > 2 && urand() < 0.8) ? 1 : 0; }
       CHECK(viekf_seq_add_frame(s, 0.0, tz.data(), N, z.data(), R.data(), 1, ids.data(), nullptr, m2.data(), nullptr));
       CHECK(viekf_seq_handle_measurements(s, nullptr, 0, nullptr));
     }
@@ -182,7 +201,14 @@ int main(int argc, char** argv) {
   late_second_sensor(yaml, 12, 5, 10);
   late_second_sensor(yaml, 13, 6, 11);
   late_second_sensor(yaml, 24, 2, 6);      // the start slot still in the ring: re-created from it
-  independent_clocks(yaml);
+  // (back is in steps + 2 ms: 9 steps back - 0.5 = 0.034 s, the flights of tests/test_gpu_sequencer.py)
+  late_second_sensor(yaml, 12, 6, 10, 7, true);
+  late_second_sensor(yaml, 12, 6, 9, 7, true);
+  late_second_sensor(yaml, 12, 5, 10, 7, true);
+  late_second_sensor(yaml, 13, 6, 11, 7, true);
+  late_second_sensor(yaml, 11, 6, 8, 7, true);
+  independent_clocks(yaml, 6);
+  independent_clocks(yaml, 300);
   std::printf("sanitized sequencer scenarios: ok\n");
   return 0;
 }

@@ -154,3 +154,78 @@ def test_propagate_to_refuses_a_participation_mask_and_device_slots_are_checked(
     assert st[1] & capi.FLAG_INTERNAL and not (st[[0, 2, 3]] & capi.FLAG_INTERNAL).any()
     x1, P1 = g.get_state(), g.get_covariance()
     assert np.array_equal(x1[1], x0[1]) and np.array_equal(P1[1], P0[1]) and np.array_equal(x1[2], x0[2])
+
+
+@pytest.mark.parametrize("N,kernel,B", [(6, 0, 7), (50, 2, 5), (30, 1, 5), (60, 0, 5), (90, 0, 4), (50, 0, 600)])
+def test_per_filter_live_slots_zero_copy_ring(N, kernel, B):
+    """viekf_batch_select_filters / _propagate_filters_to (r04: the zero-copy ring of filters on independent clocks): every filter
+    steps from ITS ring slot into ITS next one, rewinds by an index, is updated in its slot -- bit for bit what a batch that keeps
+    one live state and is stepped under the same participation masks computes; the slots left behind keep their states; getters and
+    set_state work on each filter's own slot; leaving the ring brings every live state home."""
+    steps = 4
+    sc = scene.make_scene(B, N, steps, seed=21 + N)
+    L = capi.lib()
+    from tests.helpers import apply_kernel
+
+    def make():
+        g = v.BatchVIEKF(B, N, sc["params"])
+        apply_kernel(g, kernel)
+        for i in range(N):
+            g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan))
+        return g
+
+    ga, gb = make(), make()
+    H = 6
+    ga.history_resize(H)
+    zero = np.zeros(B, dtype=np.int32)
+    capi.check(L.viekf_batch_snapshot_filters(ga._h, _p(zero), capi.HOST))
+    capi.check(L.viekf_batch_select_filters(ga._h, _p(zero)))
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())
+    live = zero.copy()
+    rng = np.random.default_rng(3)
+    hist = {}                                       # (filter, slot) -> (x, P) as the reference batch had it then
+    xb, Pb = gb.get_state(), gb.get_covariance()
+    for b in range(B):
+        hist[(b, 0)] = (xb[b].copy(), Pb[b].copy())
+    for s in range(steps):
+        mask = (rng.uniform(size=B) < 0.7).astype(np.uint8)
+        mask[0] = 1
+        dst = np.where(mask == 1, (live + 1) % H, -1).astype(np.int32)
+        u = np.ascontiguousarray(sc["u"][s]); dt = np.ascontiguousarray(sc["dt"] * (1.0 + 0.1 * s))
+        capi.check(L.viekf_batch_propagate_filters_to(ga._h, _p(u), _p(dt), _p(dst), capi.HOST))
+        live = np.where(mask == 1, dst, live).astype(np.int32)
+        capi.check(L.viekf_batch_set_active(gb._h, _p(mask), capi.HOST))
+        gb.propagate(u, dt)
+        m2 = (rng.uniform(size=B) < 0.6).astype(np.uint8)     # the frame's updates for some of the filters, in their slots
+        m2[0] = 1
+        for g in (ga, gb):
+            capi.check(L.viekf_batch_set_active(g._h, _p(m2), capi.HOST))
+            g.update_feat(sc["z"][s], sc["slot"], sc["R"])
+            capi.check(L.viekf_batch_set_active(g._h, None, capi.HOST))
+        xb, Pb = gb.get_state(), gb.get_covariance()
+        assert np.array_equal(ga.get_state(), xb) and np.array_equal(ga.get_covariance(), Pb), "step %d" % s
+        for b in range(B):
+            hist[(b, int(live[b]))] = (xb[b].copy(), Pb[b].copy())
+    assert (ga.get_status() == gb.get_status()).all()
+    # rewind: every filter to another slot of its own history (an index, no copy); the states are the ones recorded then
+    back = np.array([sorted(sl for (bb, sl) in hist if bb == b)[0] for b in range(B)], dtype=np.int32)
+    capi.check(L.viekf_batch_select_filters(ga._h, _p(back)))
+    xa, Pa = ga.get_state(), ga.get_covariance()
+    for b in range(B):
+        # (slot 0 is overwritten only if the filter's ring wrapped: H = 6 > steps + 1, it did not)
+        assert np.array_equal(xa[b], hist[(b, int(back[b]))][0]) and np.array_equal(Pa[b], hist[(b, int(back[b]))][1])
+    capi.check(L.viekf_batch_select_filters(ga._h, _p(live)))
+    # set_state on the per-filter slots: only what is given changes
+    x_new = ga.get_state()
+    x_new[:, 0] += 1.5
+    ga.set_state(x=x_new)
+    assert np.array_equal(ga.get_state(), x_new) and np.array_equal(ga.get_covariance(), Pb)
+    # whole-batch ring calls are refused in this mode; leaving the ring brings every live state home
+    assert L.viekf_batch_select(ga._h, 1) == capi.ERR_INVALID
+    u = np.ascontiguousarray(sc["u"][0]); dt = np.ascontiguousarray(sc["dt"])
+    assert L.viekf_batch_propagate_to(ga._h, _p(u), _p(dt), 1, capi.HOST) == capi.ERR_INVALID
+    assert L.viekf_batch_propagate_filters_to(ga._h, _p(u), _p(dt), _p(live), capi.HOST) == capi.ERR_INVALID   # (dst == live)
+    ga.history_resize(0)
+    assert np.array_equal(ga.get_state(), x_new) and np.array_equal(ga.get_covariance(), Pb)
+    ga.propagate(u, dt); gb.set_state(x=x_new); gb.propagate(u, dt)
+    assert np.array_equal(ga.get_state(), gb.get_state()) and np.array_equal(ga.get_covariance(), gb.get_covariance())

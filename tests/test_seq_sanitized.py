@@ -44,7 +44,7 @@ extern "C" int viekf_params_load_yaml(const char* path, viekf_params* p) {
   return VIEKF_OK;
 }
 ''' % (CSRC, CSRC))
-    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
            "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-misleading-indentation", "-I" + os.path.join(ROOT, "include"), "-o", exe,
            os.path.join(ROOT, "tests", "cpp", "seq_sanitized_driver.cpp"), os.path.join(ROOT, "tests", "cpp", "seq_host_stub.cpp"),
            os.path.join(CSRC, "viekf_seq.cpp"), os.path.join(CSRC, "viekf_yaml.cpp"), str(shim)]

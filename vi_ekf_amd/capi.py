@@ -34,6 +34,7 @@ SYMBOLS = [
     "viekf_batch_eval_h_jacobian", "viekf_batch_boxplus", "viekf_batch_boxminus", "viekf_batch_eval_reset_jacobian",
     "viekf_seq_propagate_state", "viekf_seq_set_x0", "viekf_seq_set_imu_bias", "viekf_seq_keyframe_reset",
     "viekf_seq_get_features", "viekf_seq_get_feat", "viekf_seq_drop_features", "viekf_seq_add_frame", "viekf_batch_set_async",
+    "viekf_batch_select_filters", "viekf_batch_propagate_filters_to",
 ]
 
 

@@ -87,6 +87,13 @@ struct viekf_batch {
   bool active_on = false;
   int* d_resmap = nullptr;             // fused-step kernel: block ownership map [RB][TW] of the chosen instance (build_resmap)
   int* d_ringslot = nullptr;           // [B] staging of per-filter ring slots (viekf_batch_snapshot_filters / _restore_filters)
+  // per-filter live ring slots (viekf_batch_select_filters): every filter's live (x, P) is a slot of the ring of its own; d_x / d_P
+  // then point at the ring's base and the kernels address filter b through smap[b] = slot_b * B + b (StreamArgs::si).  The map is
+  bool per_filter = false;
+  std::vector<int32_t> live_slots;     // [B] host mirror
+  int* d_smap = nullptr;               // [B] device: smap[b] = live_slots[b] * B + b, kept current in stream order by k_set_smap and by
+                                       // the fused kernel itself when it stores a filter into another slot
+  int* d_zero = nullptr;               // [B] zeros (gather / scatter between the ring and the batch's own buffers)
   // viekf_batch_set_tuning (tests / experiments; the defaults are what a caller gets)
   // async host inputs (viekf_batch_set_async): pinned staging ring the arguments are copied into at call time
   bool async_host = false;
@@ -106,6 +113,8 @@ namespace {
 
 StreamArgs make_args(const viekf_batch* b) {
   StreamArgs a;
+  a.smap = b->per_filter ? b->d_smap : nullptr;
+  a.smap_out = nullptr;
   a.x = b->d_x; a.P = b->d_P; a.len = b->d_len; a.flags = b->d_flags;
   a.Qx = b->d_Qx; a.lambda = b->d_lambda; a.ws = b->d_ws;
   a.B = b->B; a.N = b->N; a.nx = b->nx; a.nxs = b->nxs; a.n = b->n; a.ld = b->ld;
@@ -631,10 +640,11 @@ bool use_resident(const viekf_batch* b) { return (b->res_inst >= 0 || b->tile_in
 // one launch handles at most res_mcap(N) measurements; longer lists are chunked (P makes one extra HBM round trip per chunk)
 int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const double* d_dt, const double* d_z,
                     const int* d_slot, int M, const double* d_R, int r_mode, int* d_res, double* x_out = nullptr,
-                    double* P_out = nullptr, int KP = 1) {
+                    double* P_out = nullptr, int KP = 1, const int* smap_out = nullptr) {
   // (the fused kernel loads the lower triangle only and stores the lower triangle only: no symmetrisation before or after)
   StreamArgs a = make_args(b);
   if (x_out) { a.x_out = x_out; a.P_out = P_out; }   // (only meaningful for a single-chunk launch)
+  a.smap_out = smap_out;
   long rsb = 0, rsm = 0;
   if (r_mode == 1) rsb = 4;
   else if (r_mode == 2) { rsb = 4L * M; rsm = 4; }
@@ -657,6 +667,18 @@ int launch_resident(viekf_batch* b, bool do_prop, const double* d_u, const doubl
   } while (m0 < M);
   b->upper_stale = 2;
   b->stale_ever = 2;
+  return VIEKF_OK;
+}
+
+// per-filter mode: (x, P) of every filter between its live ring slot and the batch's own buffers (to_home != 0: ring -> home)
+int gather_scatter_home(viekf_batch* b, int to_home) {
+  if (!b->d_zero) {
+    HIP_TRY(hipMalloc(&b->d_zero, sizeof(int) * (size_t)b->B));
+    HIP_TRY(hipMemsetAsync(b->d_zero, 0, sizeof(int) * (size_t)b->B, b->stream));
+  }
+  StreamArgs a = make_args(b);
+  hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->home_x, b->home_P, b->d_zero, to_home, 1);
+  HIP_TRY(hipGetLastError());
   return VIEKF_OK;
 }
 
@@ -826,6 +848,8 @@ int viekf_batch_destroy(viekf_batch* b) {
   if (!b) return VIEKF_OK;
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->d_smap) (void)hipFree(b->d_smap);
+  if (b->d_zero) (void)hipFree(b->d_zero);
   void* ptrs[] = {b->home_x ? b->home_x : b->d_x, b->home_P ? b->home_P : b->d_P, b->d_Qx, b->d_lambda, b->d_Pdiag, b->d_x0, b->d_ws, b->d_len, b->d_flags, b->d_stage, b->d_dp, b->h_x, b->h_P, b->h_len, b->d_active, b->d_ringslot, b->d_resmap};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -966,14 +990,18 @@ int viekf_batch_get_state(viekf_batch* b, double* x, double* P, int32_t* len_fea
   if (int rc = check_batch(b)) return rc;
   HIP_TRY(hipSetDevice(b->device));
   const hipMemcpyKind kind = where == VIEKF_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  if (x)
-    HIP_TRY(hipMemcpy2DAsync(x, sizeof(double) * b->nx, b->d_x, sizeof(double) * b->nxs, sizeof(double) * b->nx, b->B,
-                             kind, b->stream));
-  if (P) {
-    if (int rc = ensure_full_P(b)) return rc;
-    HIP_TRY(hipMemcpy2DAsync(P, sizeof(double) * b->n, b->d_P, sizeof(double) * b->ld, sizeof(double) * b->n,
-                             (size_t)b->B * b->n, kind, b->stream));
+  const double *sx = b->d_x, *sP = b->d_P;
+  if (P) if (int rc = ensure_full_P(b)) return rc;
+  if (b->per_filter && (x || P)) {   // every filter's live slot -> the batch's own buffers, then out as usual
+    if (int rc = gather_scatter_home(b, 1)) return rc;
+    sx = b->home_x; sP = b->home_P;
   }
+  if (x)
+    HIP_TRY(hipMemcpy2DAsync(x, sizeof(double) * b->nx, sx, sizeof(double) * b->nxs, sizeof(double) * b->nx, b->B,
+                             kind, b->stream));
+  if (P)
+    HIP_TRY(hipMemcpy2DAsync(P, sizeof(double) * b->n, sP, sizeof(double) * b->ld, sizeof(double) * b->n,
+                             (size_t)b->B * b->n, kind, b->stream));
   if (len_features) HIP_TRY(hipMemcpyAsync(len_features, b->d_len, sizeof(int32_t) * b->B, kind, b->stream));
   if (where == VIEKF_HOST) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
@@ -988,12 +1016,21 @@ int viekf_batch_set_state(viekf_batch* b, const double* x, const double* P, cons
     for (int i = 0; i < b->B; i++)
       if (len_features[i] < 0 || len_features[i] > b->N)
         return fail(VIEKF_ERR_INVALID, "len_features out of range");
+  double *tx = b->d_x, *tP = b->d_P;
+  if (b->per_filter && (x || P)) {   // through the batch's own buffers: what is not given keeps its value
+    if (int rc = ensure_full_P(b)) return rc;
+    if (int rc = gather_scatter_home(b, 1)) return rc;
+    tx = b->home_x; tP = b->home_P;
+  }
   if (x)
-    HIP_TRY(hipMemcpy2DAsync(b->d_x, sizeof(double) * b->nxs, x, sizeof(double) * b->nx, sizeof(double) * b->nx, b->B,
+    HIP_TRY(hipMemcpy2DAsync(tx, sizeof(double) * b->nxs, x, sizeof(double) * b->nx, sizeof(double) * b->nx, b->B,
                              kind, b->stream));
-  if (P) {
-    HIP_TRY(hipMemcpy2DAsync(b->d_P, sizeof(double) * b->ld, P, sizeof(double) * b->n, sizeof(double) * b->n,
+  if (P)
+    HIP_TRY(hipMemcpy2DAsync(tP, sizeof(double) * b->ld, P, sizeof(double) * b->n, sizeof(double) * b->n,
                              (size_t)b->B * b->n, kind, b->stream));
+  if (b->per_filter && (x || P))
+    if (int rc = gather_scatter_home(b, 0)) return rc;
+  if (P) {
     // the kernels keep P exactly symmetric and rely on it (their rank-2 update equals the reference's Joseph form only then)
     StreamArgs a = make_args(b);
     const long tot = (long)b->n * b->n;
@@ -1391,6 +1428,11 @@ int viekf_batch_history_resize(viekf_batch* b, int32_t depth) {
   if (depth < 0 || depth > 4096) return fail(VIEKF_ERR_INVALID, "0 <= depth <= 4096");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->per_filter) {       // every filter's live slot goes home
+    if (int rc = gather_scatter_home(b, 1)) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->d_x = b->home_x; b->d_P = b->home_P; b->per_filter = false;
+  }
   if (b->live_slot >= 0) {   // the live state lives in the ring: bring it home first
     HIP_TRY(hipMemcpy(b->home_x, b->d_x, hist_nx(b), hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemcpy(b->home_P, b->d_P, hist_nP(b), hipMemcpyDeviceToDevice));
@@ -1413,6 +1455,7 @@ static int history_copy(viekf_batch* b, int32_t slot, bool save) {
   // (a covariance is copied as it stands, stale upper triangle included; what comes back from the ring is taken to be as stale
   //  as anything this batch ever produced)
   if (slot < 0 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "snapshot slot out of range (viekf_batch_history_resize first)");
+  if (b->per_filter) return fail(VIEKF_ERR_INVALID, "whole-batch ring copies under per-filter live slots (viekf_batch_select_filters)");
   if (!save) b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;
   HIP_TRY(hipSetDevice(b->device));
   const size_t nl = sizeof(int) * (size_t)b->B;
@@ -1488,6 +1531,7 @@ int viekf_batch_restore_filters(viekf_batch* b, const int32_t* slot, viekf_mem w
 int viekf_batch_select(viekf_batch* b, int32_t slot) {
   if (int rc = check_batch(b)) return rc;
   if (slot < -1 || slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+  if (b->per_filter) return fail(VIEKF_ERR_INVALID, "viekf_batch_select under per-filter live slots (viekf_batch_select_filters)");
   b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
   if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
   b->live_slot = slot;
@@ -1500,6 +1544,7 @@ int viekf_batch_propagate_to(viekf_batch* b, const double* u, const double* dt, 
   if (int rc = check_batch(b)) return rc;
   if (!u || !dt) return fail(VIEKF_ERR_INVALID, "u and dt must not be null");
   if (dst_slot < 0 || dst_slot >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
+  if (b->per_filter) return fail(VIEKF_ERR_INVALID, "viekf_batch_propagate_to under per-filter live slots (viekf_batch_propagate_filters_to)");
   if (dst_slot == b->live_slot) return viekf_batch_propagate(b, u, dt, where);
   // (a filter outside a participation mask would have nothing written into the destination slot, which then becomes the live
   //  state: the zero-copy ring is for filters that advance together)
@@ -1529,6 +1574,7 @@ int viekf_batch_propagate_n_to(viekf_batch* b, int32_t K, const double* u, const
   if (int rc = check_batch(b)) return rc;
   if (!u || !dt || !dst_slots) return fail(VIEKF_ERR_INVALID, "u, dt and dst_slots must not be null");
   if (K < 1 || K > 64) return fail(VIEKF_ERR_INVALID, "1 <= K <= 64 propagates per call");
+  if (b->per_filter) return fail(VIEKF_ERR_INVALID, "viekf_batch_propagate_n_to under per-filter live slots");
   for (int k = 0; k < K; k++) {
     if (dst_slots[k] < 0 || dst_slots[k] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range (viekf_batch_history_resize first)");
     if (dst_slots[k] == b->live_slot) return fail(VIEKF_ERR_INVALID, "a destination slot is the live slot");
@@ -1553,6 +1599,95 @@ int viekf_batch_propagate_n_to(viekf_batch* b, int32_t K, const double* u, const
   if (int rc = launch_resident(b, true, d_u, d_dt, nullptr, nullptr, 0, nullptr, 0, nullptr, slot_x(b, last), slot_P(b, last), K)) return rc;
   if (int rc = viekf_batch_select(b, last)) return rc;
   if (intermediates_written) *intermediates_written = 0;
+  if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
+  return VIEKF_OK;
+}
+
+int viekf_batch_select_filters(viekf_batch* b, const int32_t* slot) {
+  if (int rc = check_batch(b)) return rc;
+  if (!slot) return fail(VIEKF_ERR_INVALID, "slot is null");
+  if (b->hist_depth <= 0) return fail(VIEKF_ERR_INVALID, "no history ring (viekf_batch_history_resize first)");
+  if (b->live_slot >= 0) return fail(VIEKF_ERR_INVALID, "per-filter live slots need the live state in the batch's own buffers (viekf_batch_select(-1))");
+  for (int i = 0; i < b->B; i++) {
+    if (slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
+    if (slot[i] < 0 && !b->per_filter) return fail(VIEKF_ERR_INVALID, "the first call has to name a slot for every filter");
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->per_filter) {
+    if (!b->d_smap) HIP_TRY(hipMalloc(&b->d_smap, sizeof(int) * (size_t)b->B));
+    if (!b->home_x) { b->home_x = b->d_x; b->home_P = b->d_P; }
+    b->live_slots.assign((size_t)b->B, 0);
+    b->per_filter = true;
+    b->d_x = b->h_x; b->d_P = b->h_P;
+  }
+  for (int i = 0; i < b->B; i++)
+    if (slot[i] >= 0) b->live_slots[(size_t)i] = slot[i];
+  // the device's copy of the map follows in stream order (a launch of one small kernel, not a copy command between two kernels)
+  if (int rc = stage_begin(b, stage_size(sizeof(int32_t) * (size_t)b->B))) return rc;
+  const int32_t* d_slot = nullptr;
+  if (int rc = in_ptr(b, slot, (size_t)b->B, VIEKF_HOST, &d_slot)) return rc;
+  hipLaunchKernelGGL(k_set_smap, dim3((unsigned)((b->B + 255) / 256)), dim3(256), 0, b->stream, b->d_smap, d_slot, b->B);
+  HIP_TRY(hipGetLastError());
+  if (!b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
+  b->upper_stale = b->stale_ever > b->upper_stale ? b->stale_ever : b->upper_stale;   // (see history_copy)
+  return VIEKF_OK;
+}
+
+int viekf_batch_propagate_filters_to(viekf_batch* b, const double* u, const double* dt, const int32_t* dst_slot, viekf_mem where) {
+  if (int rc = check_batch(b)) return rc;
+  if (!u || !dt || !dst_slot) return fail(VIEKF_ERR_INVALID, "u, dt and dst_slot must not be null");
+  if (!b->per_filter) return fail(VIEKF_ERR_INVALID, "viekf_batch_select_filters first");
+  bool any = false;
+  for (int i = 0; i < b->B; i++) {
+    if (dst_slot[i] >= b->hist_depth) return fail(VIEKF_ERR_INVALID, "ring slot out of range");
+    if (dst_slot[i] >= 0 && dst_slot[i] == b->live_slots[(size_t)i]) return fail(VIEKF_ERR_INVALID, "a destination slot is the filter's live slot");
+    any |= dst_slot[i] >= 0;
+  }
+  if (!any) return VIEKF_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t B = (size_t)b->B;
+  // the participation mask and the destination map of THIS launch, through the pinned staging like the other per-call arguments
+  std::vector<unsigned char> act(B);
+  std::vector<int32_t> omap(B);
+  for (size_t i = 0; i < B; i++) {
+    act[i] = dst_slot[i] >= 0 ? 1 : 0;
+    omap[i] = (dst_slot[i] >= 0 ? dst_slot[i] : b->live_slots[i]) * b->B + (int32_t)i;
+  }
+  if (int rc = stage_begin(b, stage_size(sizeof(double) * 6 * B) + stage_size(sizeof(double) * B) + stage_size(B) + stage_size(sizeof(int32_t) * B) * 2))
+    return rc;
+  const double *d_u = nullptr, *d_dt = nullptr;
+  const unsigned char* d_act = nullptr;
+  const int32_t* d_omap = nullptr;
+  if (int rc = in_ptr(b, u, 6 * B, where, &d_u)) return rc;
+  if (int rc = in_ptr(b, dt, B, where, &d_dt)) return rc;
+  if (int rc = in_ptr(b, act.data(), B, VIEKF_HOST, &d_act)) return rc;
+  if (int rc = in_ptr(b, omap.data(), B, VIEKF_HOST, &d_omap)) return rc;
+  const bool saved_on = b->active_on;
+  unsigned char* saved_mask = b->d_active;
+  b->active_on = true; b->d_active = const_cast<unsigned char*>(d_act);
+  int rc = VIEKF_OK;
+  if (use_resident(b)) {     // the fused kernel loads filter b from its live slot and stores it into dst_slot[b]: no copy at all
+    rc = launch_resident(b, true, d_u, d_dt, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 1, d_omap);
+    for (size_t i = 0; i < B && rc == VIEKF_OK; i++)     // (the kernel moves the device's map entries itself)
+      if (dst_slot[i] >= 0) b->live_slots[i] = dst_slot[i];
+  } else {                   // the HBM-path family works in place: copy slot -> slot, then propagate the copy
+    const int32_t* d_dst = nullptr;
+    rc = in_ptr(b, dst_slot, B, VIEKF_HOST, &d_dst);
+    if (rc == VIEKF_OK) {
+      StreamArgs a = make_args(b);
+      hipLaunchKernelGGL(k_ring_copy, dim3(b->B), dim3(256), 0, b->stream, a, b->h_x, b->h_P, d_dst, 1, b->hist_depth);
+      if (hipGetLastError() != hipSuccess) rc = fail(VIEKF_ERR_HIP, "k_ring_copy launch failed");
+    }
+    if (rc == VIEKF_OK) {
+      for (size_t i = 0; i < B; i++)
+        if (dst_slot[i] >= 0) b->live_slots[i] = dst_slot[i];
+      hipLaunchKernelGGL(k_set_smap, dim3((unsigned)((b->B + 255) / 256)), dim3(256), 0, b->stream, b->d_smap, d_dst, b->B);
+      if (hipGetLastError() != hipSuccess) rc = fail(VIEKF_ERR_HIP, "k_set_smap launch failed");
+    }
+    if (rc == VIEKF_OK) rc = launch_propagate(b, d_u, d_dt);
+  }
+  b->active_on = saved_on; b->d_active = saved_mask;
+  if (rc) return rc;
   if (where == VIEKF_HOST && !b->async_host) HIP_TRY(hipStreamSynchronize(b->stream));
   return VIEKF_OK;
 }

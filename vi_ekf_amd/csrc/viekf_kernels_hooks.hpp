@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_eval_jacobians(StreamArgs a, const doub
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n, len = a.len[b];
-  const double* xs = x_in ? x_in + (long)b * a.nx : a.x + (long)b * a.nxs;
+  const double* xs = x_in ? x_in + (long)b * a.nx : a.x + a.si(b) * a.nxs;
   double* A = A_out ? A_out + (long)b * n * n : nullptr;
   double* G = G_out ? G_out + (long)b * n * 6 : nullptr;
   double* xd = xdot_out ? xdot_out + (long)b * n : nullptr;
@@ -62,7 +62,7 @@ __global__ void k_eval_H(StreamArgs a, const double* __restrict__ x_in, int type
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n;
-  const double* xs = x_in ? x_in + (long)b * a.nx : a.x + (long)b * a.nxs;
+  const double* xs = x_in ? x_in + (long)b * a.nx : a.x + a.si(b) * a.nxs;
   double* H = H_out + (long)b * n * 3;
   for (int e = 0; e < 3 * n; e++) H[e] = 0.0;
   const bool needs_slot = type == MT_QZETA || type == MT_FEAT || type == MT_DEPTH || type == MT_INV_DEPTH;

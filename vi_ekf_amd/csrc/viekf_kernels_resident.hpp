@@ -43,8 +43,9 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   S.mseq = reinterpret_cast<int2*>(smem + L.mseq);
   S.ctx = reinterpret_cast<BodyCtx*>(smem + L.ctx);
   S.N = a.N; S.mcap = res_mcap(a.N); S.n = a.n; S.nf = 3 * a.N; S.len = a.len[b]; S.M = M; S.mstride = m_stride; S.do_prop = do_prop & 1; S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
+  S.si = a.si(b); S.so = a.so(b);
   {
-    const double* xg = a.x + (long)b * a.nxs;
+    const double* xg = a.x + S.si * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
@@ -69,6 +70,9 @@ __device__ __forceinline__ void res_prologue(const StreamArgs& a, ResShared& S, 
   }
   RES_STAMP(S, tid == 0, 62);
   __syncthreads();
+  // per-filter live slots: the slot this launch stores the filter into is its live slot from now on (every thread of the workgroup
+  // has read the old entry above; later launches are ordered behind this one on the stream)
+  if (a.smap_out && tid == 0) a.smap[b] = (int)S.so;
   for (int mm_ = tid; mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= res_mcap(N))
     int nx = mm_ + 1;
     while (nx < M && S.mslot[nx] < 0) nx++;

@@ -31,6 +31,13 @@ struct StreamArgs {
   const unsigned char* active;   // [B] or NULL: filters with active[b] == 0 take no part in a propagate / feature-update launch
                                  // (viekf_batch_set_active: filters on different clocks share a batch)
   const int* resmap;    // fused-step kernel: ownership map of the 3x3 feature blocks, [RB][TW] entries I | J << 8 | owned << 16
+  // Per-filter live ring slots (viekf_batch_select_filters: filters on clocks of their own share a batch, each with its own ring
+  // position): x / P then point at the RING, [slot][B] entries, and filter b's state is entry smap[b] = slot_b * B + b of it.
+  // smap_out: where the fused kernel stores filter b's state (viekf_batch_propagate_filters_to: slot i_b -> slot i_b + 1, no copy).
+  int* smap;            // (device memory; the fused kernel moves a filter's entry to smap_out[b] when it stores it there)
+  const int* smap_out;
+  __device__ __forceinline__ long si(int b) const { return smap ? (long)smap[b] : (long)b; }
+  __device__ __forceinline__ long so(int b) const { return smap_out ? (long)smap_out[b] : si(b); }
 };
 
 constexpr int WK = 40;   // contraction depth of the low-rank part (16 + 16 + 6, padded to whole MFMA k-steps of 4)
@@ -106,8 +113,8 @@ __global__ __launch_bounds__(T) void k_propagate_stream(StreamArgs a, const doub
   BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
   double* Dl = xdb + 16 + (sizeof(BodyCtx) + 7) / 8;   // [N][9] Phi_ff blocks (MF only)
 
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const int nf = 3 * len, nact = 16 + nf;
   const double dt = dt_all[b];
@@ -444,8 +451,8 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
   double* K = W + 2 * n;       // [n][2]
   double* lam = K + 2 * n;     // [n]
   double* sm = lam + n;        // small scratch: zhat(2) Hb(4) res(2) Sinv(4) = 12, dxb(16)
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const int nact = 16 + 3 * len;
   unsigned flag = 0;
@@ -617,8 +624,8 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
   double* wz = smem + L.win;
   double* wR = wz + 2 * BWIN;
   int* wsl = reinterpret_cast<int*>(wR + 4 * BWIN);
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const int nact = 16 + 3 * len;
   const DevParams& prm = *a.dp;
@@ -1032,7 +1039,7 @@ __global__ __launch_bounds__(T) void k_eval_xdot(StreamArgs a, const double* __r
   double* xdb = Gb + 96;
   BodyCtx* ctx = reinterpret_cast<BodyCtx*>(xdb + 16);
   const int len = a.len[b];
-  const double* xg = a.x + (long)b * a.nxs;
+  const double* xg = a.x + a.si(b) * a.nxs;
   for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
   __syncthreads();
   if (tid == 0) {
@@ -1065,7 +1072,7 @@ __global__ __launch_bounds__(T) void k_eval_xdot(StreamArgs a, const double* __r
 __global__ void k_eval_h(StreamArgs a, int type, const int* __restrict__ slot_all, double* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
-  const double* xs = a.x + (long)b * a.nxs;
+  const double* xs = a.x + a.si(b) * a.nxs;
   const DevParams& prm = *a.dp;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
   double zhat[4] = {nan, nan, nan, nan};
@@ -1103,7 +1110,7 @@ __global__ void k_symmetrize(StreamArgs a) {
   if (b >= a.B || e >= (long)a.n * a.n) return;
   const int i = (int)(e % a.n), j = (int)(e / a.n);
   if (i <= j) return;
-  double* P = a.P + (long)b * a.n * a.ld;
+  double* P = a.P + a.si(b) * a.n * a.ld;
   const double v = 0.5 * (P[i + (long)j * a.ld] + P[j + (long)i * a.ld]);
   P[i + (long)j * a.ld] = v;
   P[j + (long)i * a.ld] = v;
@@ -1122,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
   while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
   const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
   if (ti >= nt) return;
-  double* P = a.P + (long)b * n * a.ld;
+  double* P = a.P + a.si(b) * n * a.ld;
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
   for (int c = ly; c < 32; c += 8) {
     const int i = 32 * ti + lx, j = 32 * tj + c;
@@ -1139,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_mirror_upper(StreamArgs a) {
 #ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_cov_diag(StreamArgs a, double* __restrict__ out) {
   const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[(long)b * a.n * a.ld + i + (long)i * a.ld];
+  if (b < a.B && i < a.n) out[(long)b * a.n + i] = a.P[a.si(b) * a.n * a.ld + i + (long)i * a.ld];
 }
 #endif
 
@@ -1158,8 +1165,8 @@ __global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restr
     return;
   }
   const long nP = (long)a.n * a.ld;
-  double* lx = a.x + (long)b * a.nxs;
-  double* lP = a.P + (long)b * nP;
+  double* lx = a.x + a.si(b) * a.nxs;
+  double* lP = a.P + a.si(b) * nP;
   double* rx = ring_x + ((long)sl * a.B + b) * a.nxs;
   double* rP = ring_P + ((long)sl * a.B + b) * nP;
   const double2* src = reinterpret_cast<const double2*>(to_ring ? lP : rP);   // (ld is even and the buffers 16-byte aligned)
@@ -1169,13 +1176,22 @@ __global__ __launch_bounds__(256) void k_ring_copy(StreamArgs a, double* __restr
 }
 #endif
 
+// per-filter live slots: smap[b] = slot[b] * B + b for the filters with slot[b] >= 0 (viekf_batch_select_filters: the rewind of
+// filters on clocks of their own is this index, vi_ekf_meas.cpp:50-52 per filter)
+#ifndef VIEKF_INSTANCES_ONLY
+__global__ __launch_bounds__(256) void k_set_smap(int* __restrict__ smap, const int* __restrict__ slot, int B) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < B && slot[b] >= 0) smap[b] = slot[b] * B + b;
+}
+#endif
+
 // a rectangular block P[r0 .. r0+nr, c0 .. c0+nc) of every filter -> out [B][nc][nr] (column-major per filter)
 #ifndef VIEKF_INSTANCES_ONLY
 __global__ void k_cov_block(StreamArgs a, int r0, int c0, int nr, int nc, double* __restrict__ out) {
   const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B || e >= nr * nc) return;
   const int c = e / nr, r = e - c * nr;
-  out[(long)b * nr * nc + e] = a.P[(long)b * a.n * a.ld + (r0 + r) + (long)(c0 + c) * a.ld];
+  out[(long)b * nr * nc + e] = a.P[a.si(b) * a.n * a.ld + (r0 + r) + (long)(c0 + c) * a.ld];
 }
 #endif
 
@@ -1230,8 +1246,8 @@ __global__ __launch_bounds__(T) void k_update_generic(StreamArgs a, int type, in
   double* K = W + 3 * n;        // [n][3]
   double* lam = K + 3 * n;      // [n]
   double* sm = lam + n;         // [64]: hcols (int as double) [0..5], Hc [6..23] (3 rows x 6 cols), res [24..26], ncol [27], Si [28..36], verdict [37]
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const int nact = 16 + 3 * len;
   const int slot = slot_all ? slot_all[b] : 0;
@@ -1374,12 +1390,12 @@ __global__ __launch_bounds__(T) void k_init_feature(StreamArgs a, const double* 
   const int len = a.len[b];
   if (len >= a.N) { if (ok && tid == 0) ok[b] = 0; return; }   // :9-10
   const int n = a.n, ld = a.ld;
-  double* P = a.P + (long)b * n * ld;
+  double* P = a.P + a.si(b) * n * ld;
   const int d0 = 16 + 3 * len, dmax = d0 + 3;
   if (tid == 0) {
     double q[4], rho;
     init_feature_state(pix_all + 2L * b, depth_all ? depth_all[b] : NAN, (*a.dp), q, &rho);
-    double* xf = a.x + (long)b * a.nxs + xZ + 5 * len;
+    double* xf = a.x + a.si(b) * a.nxs + xZ + 5 * len;
     xf[0] = q[0]; xf[1] = q[1]; xf[2] = q[2]; xf[3] = q[3]; xf[4] = rho;
   }
   // zero the cross strips, set the 3x3 block to P0_feat (:39-42)
@@ -1416,8 +1432,8 @@ __global__ __launch_bounds__(T) void k_keep_features(StreamArgs a, const unsigne
   double* colbuf = smem;                                   // [n]
   int* srcrow = reinterpret_cast<int*>(smem + n);          // [n] old row index of new row i (or -1)
   int* cnt = srcrow + n;
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const unsigned char* keep = keep_all + (long)b * N;
   if (tid == 0) {
@@ -1463,8 +1479,8 @@ __global__ __launch_bounds__(T) void k_keyframe_reset(StreamArgs a, const unsign
   if (b >= a.B) return;
   if (mask && !mask[b]) return;
   const int n = a.n, ld = a.ld;
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const double* q = xg + xATT;
   const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
   const double yaw = atan2(2.0 * (qw * qz + qx * qy), 1.0 - 2.0 * (qy * qy + qz * qz));     // src/quat.cpp:221-224
@@ -1517,8 +1533,8 @@ __global__ __launch_bounds__(T) void k_keyframe_reset(StreamArgs a, const unsign
 __global__ void k_reset(StreamArgs a, const double* __restrict__ x0 /*17*/, const double* __restrict__ Pdiag /*n*/) {
   const int b = blockIdx.x;
   if (b >= a.B) return;
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * a.n * a.ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * a.n * a.ld;
   for (int i = threadIdx.x; i < a.nxs; i += blockDim.x) xg[i] = (i < 17) ? x0[i] : 0.0;
   const long tot = (long)a.n * a.ld;
   for (long e = threadIdx.x; e < tot; e += blockDim.x) {

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(T) void k_propagate_wide(StreamArgs a, const double
   double* phiff = smem + L.phiff; double* Z = smem + L.Z;
   const DevParams& prm = *a.dp;
 
-  double* xg = a.x + (long)b * a.nxs;
-  double* P = a.P + (long)b * n * ld;
+  double* xg = a.x + a.si(b) * a.nxs;
+  double* P = a.P + a.si(b) * n * ld;
   const int len = a.len[b];
   const int nf = 3 * len, nact = 16 + nf;
   const double dt = dt_all[b];

@@ -145,6 +145,7 @@ struct ResShared {  // resolved LDS pointers + launch constants shared by both r
   int2* mseq;   // [res_mcap(N)] {index of the next measurement that runs (or M), its slot (or -1)}: one LDS read per iteration
   BodyCtx* ctx;
   int N, n, nf, len, M, mstride, do_prop, b, dbg, kp, B, img_len, mcap;   // kp: propagates per launch (viekf_batch_step_n)
+  long si, so;   // the filter's entry of x / P it is loaded from and stored to (StreamArgs::si / so, read ONCE in the prologue)
   double* stamps;
 };
 

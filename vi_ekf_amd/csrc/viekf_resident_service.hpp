@@ -399,8 +399,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
   __syncthreads();  // B5
   RES_STAMP(S, lane == 0, 12);
   // ---------------- store x, status ----------------
-  double* xg = a.x_out + (long)S.b * a.nxs;
-  const int xend = (a.x_out != a.x) ? a.nxs : xZ + 5 * len;   // another ring slot gets the whole vector (zeros past the features)
+  double* xg = a.x_out + S.so * a.nxs;
+  const int xend = (a.x_out != a.x || a.smap_out) ? a.nxs : xZ + 5 * len;   // another ring slot gets the whole vector (zeros past the features)
   for (int i = lane; PRIMARY && i < xend; i += 64) {
     const double v = xs[i];
     if (v != v) flag |= FLAG_NAN;

@@ -26,7 +26,7 @@ __device__ __forceinline__ bool store_chunk_at(int f0, int N, int n, int img_len
 template <int T>
 __device__ __forceinline__ void res_store_chunk(const StreamArgs& a, const ResShared& S, const StoreChunk& c, int tid) {
   const int n = S.n, ld = a.ld;
-  double* P = a.P_out + (long)S.b * n * ld;
+  double* P = a.P_out + S.so * n * ld;
   const double* img = S.Z;
   const int ncol = 3 * (c.f1 - c.f0), lane = tid & 63, w = tid >> 6;
   constexpr int NWV = T / 64;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void res_body_items(const ResShared& S, const double*
 template <int RB, int TW, bool MP, int T = TW + 64, bool ZU = false>
 __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared& S, int tid) {
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len;
-  double* P = a.P + (long)S.b * n * ld;
+  double* P = a.P + S.si * n * ld;
   // SYMMETRIC ownership: of each unordered pair of feature blocks {I,J} only one is kept (I >= J); which thread keeps it in
   // which of its RB slots is a table built by the host (build_resmap, viekf_capi.hip: 8 x 8 tiles of blocks per (slot, wave)
   // group, so that the column pair of one feature is published from few groups).  Slot a = 0 of the threads t < N is the
@@ -493,7 +493,7 @@ __device__ __forceinline__ void res_worker(const StreamArgs& a, const ResShared&
   // ---------------- store ----------------
   // (indices re-derived from opaque copies: otherwise the load addresses are kept alive -- spilled -- all kernel long)
   {
-    P = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
+    P = a.P_out + S.so * n * ld;   // in place, or the next slot of the history ring
     for (int e = opaque(tid); e < nf * 16; e += TW) {     // body columns, coalesced along rows
       const int k = e / nf, row = e - k * nf;
       P[(16 + row) + (long)k * ld] = Pbc[row * 16 + k];

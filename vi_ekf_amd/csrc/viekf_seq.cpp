@@ -11,12 +11,21 @@
 #include <deque>
 #include <fstream>
 #include <functional>
+#include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
 #include "../../include/viekf.h"
+
+#ifdef VIEKF_SEQ_TRACE
+#include <cstdio>
+#define TR(...) std::fprintf(stderr, __VA_ARGS__)
+#else
+#define TR(...) do {} while (0)
+#endif
 
 namespace {
 
@@ -97,6 +106,17 @@ void add_adj_cov(const double* T, const double* C, double* out) {
 // Independent clocks (viekf_seq_create_independent): every filter keeps its own time ring, input deque and measurement queue
 // -- the reference class's members, one set per filter -- and the device work of a call is batched over the filters that
 // take the same kind of step.
+// A camera frame handed over by viekf_seq_add_frame, shared by the queues of all filters that took entries from it: the pixels
+// are stored once, every filter's queue holds ONE entry that points here (r04: 50 queue entries of 136 bytes per filter and frame,
+// copied again into the step list, were most of the host time of this mode).  Rows are in PROCESSING order (the reverse of the
+// insertion order, vi_ekf_meas.cpp:150-176 with :16-18,96-98): member j of row b is feature count - 1 - j of the call.
+struct FrameData {
+  int count = 0;
+  std::vector<double> z;              // [B][count][2]
+  std::vector<int32_t> id;            // [B][count]
+  std::vector<uint8_t> present;       // [B][count]: this filter queued the member (not NaN, a tracked feature, not before its start)
+  double R[4] = {};
+};
 struct FMeas {                        // measurement_t, include/vi_ekf.h:167-179 (one filter)
   double t;
   int type, zdim, rdim;
@@ -104,19 +124,27 @@ struct FMeas {                        // measurement_t, include/vi_ekf.h:167-179
   bool active;
   int32_t id;
   bool handled;
+  std::shared_ptr<const FrameData> frame;   // set: a frame block -- members [first, frame->count) of this filter's row
+  int first = 0;
+  int weight = 1;                     // how many measurements of the reference's queue this entry stands for (:121-122)
 };
+struct FInput { double t; double u[6]; };   // (t, rotated u), vi_ekf.cpp:269-272
 struct FilterSeq {
   std::vector<double> t;                                           // t_ ring
   int i = 0;                                                       // i_
   double start_t = NAN;
-  std::deque<std::pair<double, std::vector<double>>> u;            // (t, rotated u [6]), newest first
+  std::deque<FInput> u;                                            // newest first
   std::deque<FMeas> zbuf;                                          // newest first
+  long queued = 0;                                                 // sum of the entries' weights = zbuf_.size() of the reference
 };
 struct SeqOp {                        // one device step of one filter's handle_measurements, in the order it must run
   enum Kind { REWIND, PROP, FEAT_FRAME, GENERIC } kind;
   int slot = -1;                      // REWIND: ring slot to restore;  PROP: ring slot to record into
   double u[6] = {}, dt = 0.0;         // PROP
-  std::vector<FMeas> meas;            // FEAT_FRAME: the frame's entries in processing order;  GENERIC: one entry
+  std::vector<FMeas> meas;            // FEAT_FRAME from single entries: in processing order;  GENERIC: one entry
+  std::shared_ptr<const FrameData> frame;   // FEAT_FRAME from a frame block: members [first, frame->count) of the filter's row
+  int first = 0;
+  int count() const { return frame ? frame->count - first : (int)meas.size(); }
 };
 
 struct viekf_seq {
@@ -243,6 +271,7 @@ void before_overwrite(viekf_seq* s, int ip) {
   s->orph = true;
   s->orph_t = s->t[ip];
   std::swap(s->extra, s->phys[ip]);
+  TR("  orphan: slot %d (t %.4f) leaves the ring, %zu steps kept, its buffer %d, slot gets %d\n", ip, s->orph_t, s->orph_steps.size(), s->extra, s->phys[ip]);
 }
 
 // numeric core of propagate_state (vi_ekf.cpp:291-311) with ring bookkeeping; `u` is what the caller hands to
@@ -274,6 +303,7 @@ int propagate_core(viekf_seq* s, const double* u, double t, bool save_input) {
   }
   const int ip = (s->i + 1) % s->H;                                // :298: x_[ip], P_[ip] are written from x_[i_], P_[i_] --
   before_overwrite(s, ip);
+  TR("  prop: slot %d (buf %d, t %.4f) -> slot %d (buf %d, t %.4f)\n", s->i, s->phys[s->i], s->t[s->i], ip, s->phys[ip], t);
   if (int rc = viekf_batch_propagate_to(s->core, u, dts.data(), s->phys[ip], VIEKF_HOST)) return rc;   // the old slot stays as history
   s->i = ip;                                                       // :306
   s->t[s->i] = t;
@@ -319,6 +349,7 @@ int replay_inputs(viekf_seq* s, size_t from) {
       pslots[k] = s->phys[slots[k]];
     }
     int32_t written = 1;
+    TR("  replay: %d steps from slot %d (buf %d, t %.4f) into slots %d.. (last buf %d)\n", K, s->i, s->phys[s->i], s->t[s->i], slots[0], pslots[K - 1]);
     if (int rc = viekf_batch_propagate_n_to(s->core, K, U.data(), DT.data(), pslots.data(), &written, VIEKF_HOST)) return rc;
     for (int k = 0; k < K; k++) {
       s->t[slots[k]] = s->u[idx[done + k]].first;
@@ -339,6 +370,7 @@ int replay_inputs(viekf_seq* s, size_t from) {
 int rewind_to(viekf_seq* s, int target, bool* found) {
   const int H = s->H, B = s->B;
   *found = true;
+  TR("rewind to slot %d (t %.4f, mat %d) from slot %d\n", target, s->t[target], (int)s->mat[target], s->i);
   if (s->mat[target]) {
     if (target != s->i) {
       if (int rc = viekf_batch_select(s->core, s->phys[target])) return rc;
@@ -482,10 +514,11 @@ int update_block(viekf_seq* s, SeqMeas& m, std::vector<int32_t>* res) {
 bool plan_propagate(viekf_seq* s, int b, const double* u_in, double t, bool save_input, double* dt_out, int* dst_slot) {
   FilterSeq& f = s->fs[b];
   if (save_input) {
-    std::vector<double> ub(6);
-    rota(s->prm.q_b_u, u_in, ub.data());
-    rota(s->prm.q_b_u, u_in + 3, ub.data() + 3);
-    f.u.emplace_front(t, std::move(ub));                           // :269-272 (the ROTATED input is stored)
+    FInput in;
+    in.t = t;
+    rota(s->prm.q_b_u, u_in, in.u);
+    rota(s->prm.q_b_u, u_in + 3, in.u + 3);
+    f.u.push_front(in);                                            // :269-272 (the ROTATED input is stored)
   }
   if (std::isnan(f.start_t)) { f.start_t = t; f.t[f.i] = t; return false; }   // :274-279
   const double dt = t - f.t[f.i];
@@ -502,11 +535,11 @@ bool plan_propagate(viekf_seq* s, int b, const double* u_in, double t, bool save
 // times, handled flags, queue trims) is done here, the steps run afterwards, batched over the filters
 void plan_handle(viekf_seq* s, int b, std::vector<SeqOp>& ops) {
   FilterSeq& f = s->fs[b];
-  auto prop = [&](const std::vector<double>& ur, double t) {       // propagate_state(u, t, false): replays are not stored again
+  auto prop = [&](const double* ur, double t) {                     // propagate_state(u, t, false): replays are not stored again
     SeqOp op;
     op.kind = SeqOp::PROP;
-    if (plan_propagate(s, b, ur.data(), t, false, &op.dt, &op.slot)) {
-      std::memcpy(op.u, ur.data(), sizeof op.u);
+    if (plan_propagate(s, b, ur, t, false, &op.dt, &op.slot)) {
+      std::memcpy(op.u, ur, sizeof op.u);
       ops.push_back(std::move(op));
     }
   };
@@ -514,20 +547,20 @@ void plan_handle(viekf_seq* s, int b, std::vector<SeqOp>& ops) {
   long zi = (long)f.zbuf.size() - 1;                               // :16-18 oldest unhandled
   while (f.zbuf[zi].handled && zi != 0) zi--;
   if (zi == 0 && f.zbuf[zi].handled) return;                       // :21-22
-  if (f.zbuf[zi].t > f.u[0].first) return;                         // :24-28 from the future
+  if (f.zbuf[zi].t > f.u[0].t) return;                             // :24-28 from the future
   size_t ui = 0;                                                   // :32-38 input just before the measurement
   while (ui != f.u.size()) {
-    if (f.zbuf[zi].t > f.u[ui].first) break;
+    if (f.zbuf[zi].t > f.u[ui].t) break;
     ui++;
   }
-  if (ui == f.u.size() || f.zbuf[zi].t <= f.u[ui].first) return;   // :39-43 not enough input history
+  if (ui == f.u.size() || f.zbuf[zi].t <= f.u[ui].t) return;       // :39-43 not enough input history
   int k = s->H, target = -1;                                       // :46-57 rewind
   while (k > 0) {
     const int j = (f.i + k) % s->H;
-    if (f.t[j] <= f.u[ui].first) { target = j; break; }
+    if (f.t[j] <= f.u[ui].t) { target = j; break; }
     k--;
   }
-  if (k == 0) { f.zbuf.erase(f.zbuf.begin() + zi); return; }       // :59-64 not enough state history
+  if (k == 0) { f.queued -= f.zbuf[zi].weight; f.zbuf.erase(f.zbuf.begin() + zi); return; }   // :59-64 not enough state history
   if (target != f.i) {
     SeqOp op;
     op.kind = SeqOp::REWIND;
@@ -535,40 +568,56 @@ void plan_handle(viekf_seq* s, int b, std::vector<SeqOp>& ops) {
     ops.push_back(std::move(op));
     f.i = target;
   }
-  auto mate = [](const FMeas& a, const FMeas& z) {                 // entries of one camera frame (see update_frame)
-    return !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim &&
+  auto mate = [](const FMeas& a, const FMeas& z) {                 // single entries of one camera frame (see update_frame)
+    return !a.frame && !a.handled && a.type == VIEKF_FEAT && a.active && a.t == z.t && a.zdim == z.zdim && a.rdim == z.rdim &&
            std::memcmp(a.R, z.R, sizeof(double) * 4) == 0;
   };
   ui--;                                                            // :74
   while (ui != 0) {                                                // :75
     bool left_inner_by_break = false;
-    while (f.zbuf[zi].t <= f.u[ui].first) {                        // :78
+    while (f.zbuf[zi].t <= f.u[ui].t) {                            // :78
       FMeas& z = f.zbuf[zi];
-      if (f.t[f.i] < z.t) prop(f.u[ui].second, z.t);               // :81-82
+      if (f.t[f.i] < z.t) prop(f.u[ui].u, z.t);                    // :81-82
       if (!z.handled) {                                            // :87-95
         SeqOp op;
-        long zl = zi;
-        if (z.type == VIEKF_FEAT && z.active)
-          while (zl > 0 && mate(f.zbuf[zl - 1], z)) zl--;
-        op.kind = (z.type == VIEKF_FEAT && z.active) ? SeqOp::FEAT_FRAME : SeqOp::GENERIC;
-        op.slot = f.i;   // an update changes x_[i_], P_[i_] in place (vi_ekf_meas.cpp:254-271): the ring slot is refreshed after it
-        for (long q = zi; q >= zl; q--) { f.zbuf[q].handled = true; op.meas.push_back(f.zbuf[q]); }   // :198
+        op.slot = f.i;   // (an update changes x_[i_], P_[i_] in place, vi_ekf_meas.cpp:254-271: that slot IS the filter's live state)
+        if (z.frame) {   // a frame block: its members in one launch, nothing copied
+          op.kind = SeqOp::FEAT_FRAME;
+          op.frame = z.frame;
+          op.first = z.first;
+          z.handled = true;                                        // :198
+        } else {
+          long zl = zi;
+          if (z.type == VIEKF_FEAT && z.active)
+            while (zl > 0 && mate(f.zbuf[zl - 1], z)) zl--;
+          op.kind = (z.type == VIEKF_FEAT && z.active) ? SeqOp::FEAT_FRAME : SeqOp::GENERIC;
+          for (long q = zi; q >= zl; q--) { f.zbuf[q].handled = true; op.meas.push_back(f.zbuf[q]); }   // :198
+          zi = zl;
+        }
         ops.push_back(std::move(op));
-        zi = zl;
       }
       if (zi != 0) {                                               // :97-105
         zi--;
-        while (f.u[ui].first < f.zbuf[zi].t && ui != 0) { prop(f.u[ui].second, f.u[ui].first); ui--; }
+        while (f.u[ui].t < f.zbuf[zi].t && ui != 0) { prop(f.u[ui].u, f.u[ui].t); ui--; }
       } else {                                                     // :106-115
-        while (ui != 0) { prop(f.u[ui].second, f.u[ui].first); ui--; }
+        while (ui != 0) { prop(f.u[ui].u, f.u[ui].t); ui--; }
         left_inner_by_break = true;
         break;
       }
     }
     if (!left_inner_by_break) break;
   }
-  prop(f.u[ui].second, f.u[ui].first);                             // :118
-  while ((int)f.zbuf.size() > s->MH) f.zbuf.pop_back();            // :121-122
+  prop(f.u[ui].u, f.u[ui].t);                                      // :118
+  while (f.queued > s->MH && !f.zbuf.empty()) {                    // :121-122: single measurements leave from the old end; a frame
+    FMeas& e = f.zbuf.back();                                      // block gives up the members it would consume first
+    const long drop = f.queued - s->MH;
+    if (drop >= e.weight) { f.queued -= e.weight; f.zbuf.pop_back(); continue; }
+    const uint8_t* pr = e.frame->present.data() + (size_t)b * e.frame->count;
+    long left = drop;
+    while (left > 0 && e.first < e.frame->count) { if (pr[e.first]) left--; e.first++; }
+    e.weight -= (int)drop;
+    f.queued -= drop;
+  }
   while ((int)f.u.size() > s->H) f.u.pop_back();                   // :125-126
 }
 
@@ -596,13 +645,10 @@ int reset_and_move_node(viekf_seq* s, const std::vector<uint8_t>& reset, double*
 }
 
 // independent clocks: the reference changes x_[i_], P_[i_] in place (updates, init_feature, clear_feature, keyframe reset), and
-// that slot is what a later rewind finds; here the ring holds copies, so the current slot of the touched filters is refreshed
-int refresh_slots(viekf_seq* s, const std::vector<uint8_t>& touched) {
-  std::vector<int32_t> slot(s->B, -1);
-  bool any = false;
-  for (int b = 0; b < s->B; b++)
-    if (touched[b]) { slot[b] = s->fs[b].i; any = true; }
-  return any ? viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST) : VIEKF_OK;
+// that slot is what a later rewind finds
+int refresh_slots(viekf_seq*, const std::vector<uint8_t>&) {
+  // (r04: every filter's live state IS its ring slot -- viekf_batch_select_filters -- so an in-place change is already there)
+  return VIEKF_OK;
 }
 
 // runs the planned steps: per round the next step of every filter, one masked launch per kind of step
@@ -628,7 +674,7 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
     std::vector<uint8_t> done(B, 0);
     if (group(SeqOp::REWIND, 0)) {
       for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
-      if (int rc = viekf_batch_restore_filters(s->core, slot.data(), VIEKF_HOST)) return rc;
+      if (int rc = viekf_batch_select_filters(s->core, slot.data())) return rc;   // the rewind (:50-52): an index per filter
       for (int b = 0; b < B; b++) done[b] |= mask[b];
     }
     if (group(SeqOp::PROP, 0)) {
@@ -640,18 +686,15 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
         slot[b] = ops[b][head[b]].slot;
       }
       for (int b = 0; b < B; b++) if (!mask[b]) slot[b] = -1;
-      if (int rc = viekf_batch_set_active(s->core, mask.data(), VIEKF_HOST)) return rc;
-      int rc = viekf_batch_propagate(s->core, u.data(), dt.data(), VIEKF_HOST);
-      (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
-      if (rc) return rc;
-      if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
+      // x_[ip], P_[ip] written from x_[i_], P_[i_] (vi_ekf.cpp:298-306) for every filter that steps: slot i_b -> slot i_b + 1
+      if (int rc = viekf_batch_propagate_filters_to(s->core, u.data(), dt.data(), slot.data(), VIEKF_HOST)) return rc;
       for (int b = 0; b < B; b++) done[b] |= mask[b];
     }
     if (group(SeqOp::FEAT_FRAME, 0)) {
       int M = 0;
       for (int b = 0; b < B; b++) {
         if (done[b]) mask[b] = 0;
-        if (mask[b]) M = std::max(M, (int)ops[b][head[b]].meas.size());
+        if (mask[b]) M = std::max(M, ops[b][head[b]].count());
       }
       if (M > 0) {
         // R may differ between filters: r_mode 1 (one R per filter)
@@ -660,6 +703,15 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
         for (int b = 0; b < B; b++) {
           if (!mask[b]) continue;
           const SeqOp& op = ops[b][head[b]];
+          if (op.frame) {
+            const FrameData& fd = *op.frame;
+            const int cnt = fd.count - op.first;
+            const size_t row = (size_t)b * fd.count + op.first;
+            std::memcpy(R.data() + 4 * (size_t)b, fd.R, sizeof(double) * 4);
+            std::memcpy(z.data() + (size_t)b * M * 2, fd.z.data() + row * 2, sizeof(double) * 2 * (size_t)cnt);
+            for (int j = 0; j < cnt; j++) sl[(size_t)b * M + j] = fd.present[row + j] ? local_id(s, b, fd.id[row + j]) : -1;
+            continue;
+          }
           std::memcpy(R.data() + 4 * (size_t)b, op.meas[0].R, sizeof(double) * 4);
           for (size_t j = 0; j < op.meas.size(); j++) {
             z[((size_t)b * M + j) * 2] = op.meas[j].z[0];
@@ -672,13 +724,12 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
         int rc = viekf_batch_update_feat(s->core, z.data(), sl.data(), M, R.data(), 1, want_gated ? res.data() : nullptr, VIEKF_HOST);
         (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
         if (rc) return rc;
-        for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
-        if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
         for (int b = 0; b < B; b++) {
           if (!mask[b]) continue;
           const SeqOp& op = ops[b][head[b]];
-          for (size_t j = 0; want_gated && j < op.meas.size(); j++)
-            if (res[(size_t)b * M + j] == VIEKF_MEAS_GATED) gated[b].push_back(op.meas[j].id);
+          for (int j = 0; want_gated && j < op.count(); j++)
+            if (res[(size_t)b * M + j] == VIEKF_MEAS_GATED)
+              gated[b].push_back(op.frame ? op.frame->id[(size_t)b * op.frame->count + op.first + j] : op.meas[(size_t)j].id);
           done[b] = 1;
         }
       }
@@ -707,8 +758,6 @@ int run_ops(viekf_seq* s, std::vector<std::vector<SeqOp>>& ops, std::vector<std:
       if (int rc = viekf_batch_update(s->core, type, z.data(), zdim, R.data(), rdim, 1, needs_slot ? sl.data() : nullptr, act.data(),
                                       res.data(), VIEKF_HOST))
         return rc;
-      for (int b = 0; b < B; b++) slot[b] = mask[b] ? ops[b][head[b]].slot : -1;
-      if (int rc2 = viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST)) return rc2;
       for (int b = 0; b < B; b++) {
         if (!mask[b]) continue;
         if (type == VIEKF_FEAT && res[b] == VIEKF_MEAS_GATED) gated[b].push_back(ops[b][head[b]].meas[0].id);
@@ -778,6 +827,7 @@ int viekf_seq_create_independent(viekf_batch* core, int32_t state_hist, int32_t 
   for (auto& f : s->fs) f.t.assign(state_hist, NAN);               // vi_ekf.cpp:22-27
   std::vector<int32_t> zero(B, 0);
   if (int rc = viekf_batch_snapshot_filters(core, zero.data(), VIEKF_HOST)) { delete s; return rc; }   // x_[0], P_[0]
+  if (int rc = viekf_batch_select_filters(core, zero.data())) { delete s; return rc; }                 // ... ARE the live state
   s->ids.assign(B, {});
   s->slot_of.assign(B, {});
   s->next_id.assign(B, 0);
@@ -802,11 +852,7 @@ int viekf_seq_propagate_t(viekf_seq* s, const double* u, const double* t, const 
     if (plan_propagate(s, b, u + 6 * (size_t)b, t[b], true, &dt[b], &slot[b])) { act[b] = 1; any = true; }
   }
   if (!any) return VIEKF_OK;
-  if (int rc = viekf_batch_set_active(s->core, act.data(), VIEKF_HOST)) return rc;
-  int rc = viekf_batch_propagate(s->core, u, dt.data(), VIEKF_HOST);
-  (void)viekf_batch_set_active(s->core, nullptr, VIEKF_HOST);
-  if (rc) return rc;
-  return viekf_batch_snapshot_filters(s->core, slot.data(), VIEKF_HOST);   // x_[ip], P_[ip] of every filter that stepped
+  return viekf_batch_propagate_filters_to(s->core, u, dt.data(), slot.data(), VIEKF_HOST);   // x_[ip], P_[ip] of every filter that steps
 }
 
 int viekf_seq_add_measurement_t(viekf_seq* s, const double* t, int32_t type, const double* z, int32_t zdim, const double* R,
@@ -840,6 +886,7 @@ int viekf_seq_add_measurement_t(viekf_seq* s, const double* t, int32_t type, con
     size_t k = 0;                                                                    // :150-156
     while (k < f.zbuf.size() && !(f.zbuf[k].t < m.t)) k++;
     f.zbuf.insert(f.zbuf.begin() + (long)k, m);                                      // :169-175
+    f.queued += 1;
   }
   if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
     std::vector<double> dep(B, NAN);
@@ -968,22 +1015,28 @@ int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int3
     }
     return VIEKF_OK;
   }
-  if (s->indep && count > 1) {
-    // independent clocks: the same per-feature tests in the same order (viekf_seq_add_measurement_t), but every filter's accepted
-    // entries go into its queue in ONE insertion -- entry by entry each insert moves the frame's earlier entries (same time stamp:
-    // the new one goes behind them, vi_ekf_meas.cpp:150-156), 50 x 1024 shifts of a few KB per frame
-    std::vector<std::vector<FMeas>> add(B);
+  if (s->indep && count > 1 && active) {
+    // independent clocks: the same per-feature tests in the same order (viekf_seq_add_measurement_t); the frame's pixels are stored
+    // ONCE (FrameData) and every filter that accepted members queues one entry pointing at its row
+    auto fd = std::make_shared<FrameData>();
+    fd->count = count;
+    fd->z.assign((size_t)B * count * 2, 0.0);
+    fd->id.assign((size_t)B * count, -1);
+    fd->present.assign((size_t)B * count, 0);
+    std::memcpy(fd->R, R, sizeof(double) * 4);
+    std::vector<int> npres(B, 0);
     std::vector<uint8_t> newf(B);
     std::vector<double> zk((size_t)B * 2), dk((size_t)B, NAN);
     std::vector<int32_t> ok(B);
     for (int k = 0; k < count; k++) {
+      const int j = count - 1 - k;                                 // position in processing order (last added is consumed first)
       bool any_new = false;
       for (int b = 0; b < B; b++) {
-        const size_t e = (size_t)b * count + k;
+        const size_t e = (size_t)b * count + k, o = (size_t)b * count + j;
         newf[b] = 0;
         if (result) result[e] = VIEKF_MEAS_SKIPPED;
         if (mask && !mask[b]) continue;
-        FilterSeq& f = s->fs[b];
+        const FilterSeq& f = s->fs[b];
         const double tb = t_per_filter ? t_per_filter[b] : t;
         int32_t r = VIEKF_MEAS_SUCCESS;
         if (tb < f.start_t) r = VIEKF_MEAS_INVALID;                                   // :133-134
@@ -992,14 +1045,11 @@ int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int3
           r = VIEKF_MEAS_NEW_FEATURE;
           if ((int)s->ids[b].size() < s->N) { newf[b] = 1; any_new = true; }          // vi_ekf_feat.cpp:9-10
         } else {
-          FMeas m;
-          m.t = tb; m.type = VIEKF_FEAT; m.zdim = 2; m.rdim = 2; m.active = active != 0; m.handled = false; m.id = id[e];
-          std::memset(m.z, 0, sizeof m.z);
-          std::memset(m.R, 0, sizeof m.R);
-          m.z[0] = z[2 * e]; m.z[1] = z[2 * e + 1];
-          std::memcpy(m.R, R, sizeof(double) * 4);
-          add[b].push_back(m);
+          fd->present[o] = 1;
+          npres[b]++;
         }
+        fd->z[2 * o] = z[2 * e]; fd->z[2 * o + 1] = z[2 * e + 1];
+        fd->id[o] = id[e];
         if (result) result[e] = r;
       }
       if (any_new) {   // init_feature at the CURRENT state (vi_ekf_feat.cpp:6-47); numbered by the filter itself (:29-30)
@@ -1011,15 +1061,21 @@ int viekf_seq_add_frame(viekf_seq* s, double t, const double* t_per_filter, int3
         if (int rc = viekf_batch_init_feature(s->core, zk.data(), dk.data(), newf.data(), ok.data(), VIEKF_HOST)) return rc;
         for (int b = 0; b < B; b++)
           if (newf[b] && ok[b]) push_feature(s, b);
-        if (int rc = refresh_slots(s, newf)) return rc;
       }
     }
     for (int b = 0; b < B; b++) {
-      if (add[b].empty()) continue;
+      if (!npres[b]) continue;
       FilterSeq& f = s->fs[b];
+      FMeas m;
+      m.t = t_per_filter ? t_per_filter[b] : t; m.type = VIEKF_FEAT; m.zdim = 2; m.rdim = 2; m.active = true; m.handled = false; m.id = -1;
+      std::memset(m.z, 0, sizeof m.z);
+      std::memset(m.R, 0, sizeof m.R);
+      std::memcpy(m.R, R, sizeof(double) * 4);
+      m.frame = fd; m.first = 0; m.weight = npres[b];
       size_t k = 0;                                                                    // :150-156
-      while (k < f.zbuf.size() && !(f.zbuf[k].t < add[b][0].t)) k++;
-      f.zbuf.insert(f.zbuf.begin() + (long)k, add[b].begin(), add[b].end());           // :169-175
+      while (k < f.zbuf.size() && !(f.zbuf[k].t < m.t)) k++;
+      f.zbuf.insert(f.zbuf.begin() + (long)k, std::move(m));                           // :169-175
+      f.queued += npres[b];
     }
     return VIEKF_OK;
   }
@@ -1076,7 +1132,16 @@ int viekf_seq_handle_measurements(viekf_seq* s, int32_t* gated_ids, int32_t cap,
   };
   if (s->indep) {   // every filter plans its own rewind / replay; the device steps run batched by kind
     std::vector<std::vector<SeqOp>> ops(B);
-    for (int b = 0; b < B; b++) plan_handle(s, b, ops[b]);
+    // (the filters' queues are separate objects: planned side by side on a few host threads when there are many of them)
+    const int nth = B >= 256 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nth > 1) {
+      std::vector<std::thread> pool;
+      for (int w = 0; w < nth; w++)
+        pool.emplace_back([&, w]() { for (int b = B * w / nth; b < B * (w + 1) / nth; b++) { ops[b].reserve(16); plan_handle(s, b, ops[b]); } });
+      for (auto& th : pool) th.join();
+    } else {
+      for (int b = 0; b < B; b++) plan_handle(s, b, ops[b]);
+    }
     if (int rc = run_ops(s, ops, gated, gated_ids != nullptr || gated_count != nullptr)) return rc;
     return finish();
   }

@@ -102,8 +102,9 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
   S.N = a.N; S.mcap = res_mcap(a.N); S.n = a.n; S.nf = 3 * a.N; S.len = present ? a.len[b] : 0; S.M = present ? M : 0; S.mstride = m_stride; S.do_prop = do_prop & 1;
   S.dbg = (do_prop >> 8) & 0xff; S.kp = (do_prop >> 16) > 0 ? (do_prop >> 16) : 1; S.B = a.B; S.b = b; S.stamps = a.ws;
   S.NT = tile_nt(a.N); S.NQ = 16 * S.NT;
+  S.si = present ? a.si(b) : 0; S.so = present ? a.so(b) : 0;
   if (present) {
-    const double* xg = a.x + (long)b * a.nxs;
+    const double* xg = a.x + S.si * a.nxs;
     for (int i = tid; i < a.nxs; i += T) S.xs[i] = (i < xZ + 5 * S.len) ? xg[i] : 0.0;
     for (int i = tid; i < a.n; i += T) S.lam[i] = a.lambda[i];
     for (int i = tid; i < 2 * a.N; i += T) { S.fixadd[i] = 0.0; S.fixset[i] = 0.0; }
@@ -123,6 +124,7 @@ __device__ __forceinline__ void tile_prologue(const StreamArgs& a, TileShared& S
     }
   }
   __syncthreads();
+  if (present && a.smap_out && tid == 0) a.smap[b] = (int)S.so;   // (see res_prologue)
   for (int mm_ = tid; present && mm_ < M; mm_ += T) {   // successor table (each entry scans forward; M <= res_mcap(N))
     int nx = mm_ + 1;
     while (nx < M && S.mslot[nx] < 0) nx++;

@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
   const int N = S.N, n = S.n, ld = a.ld, nf = S.nf, len = S.len, NQ = S.NQ;
   const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const DevParams& prm = *a.dp;
-  double* P = a.P + (long)S.b * n * ld;
+  double* P = a.P + S.si * n * ld;
   double* Pbc = S.Pbc;   // [nf][16]  P[16+row][k]: the body columns, in LDS during load and propagate
   double* Pbb = S.Pbb;   // [16][16]  row-major P_bb
   (void)TPW;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void tile_worker(const StreamArgs& a, const TileShare
 
   // ---------------- store: the lower triangle, straight from the tiles (lanes along the rows of P) ----------------
   {
-    double* Po = a.P_out + (long)S.b * n * ld;   // in place, or the next slot of the history ring
+    double* Po = a.P_out + S.so * n * ld;   // in place, or the next slot of the history ring
     const LaneOff so_ = lane_off();
     static_for<CNT>([&](auto sc) {
       constexpr int s = decltype(sc)::value, TI = Map::ti(W, s), TJ = Map::tj(W, s);
