@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="filters per GPU")
     ap.add_argument("--feat", type=int, default=50, help="N_feat")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 streaming, 2 resident")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="viekf_batch_set_tuning(KEY, VALUE) on the benchmarked batch (integers, include/viekf.h VIEKF_TUNE_*): A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cadence run (profiling: keeps the kernel statistics to the timed steps)")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
@@ -304,6 +306,9 @@ def main():
     g = v.BatchVIEKF(B, N, params, device=dev_index)
     if args.kernel:
         g.set_kernel(args.kernel)
+    for kv in args.tune:
+        key, value = kv.split("=")
+        g.set_tuning(int(key), int(value))
     g.use_torch_stream()
     desc = g.describe()
     d_u = torch.tensor(sc["u"], device=dev)

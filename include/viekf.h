@@ -133,11 +133,14 @@ int viekf_batch_set_kernel(viekf_batch *b, int32_t family);
  *   VIEKF_TUNE_BLOCK_GROUP   measurements per pass of the grouped wide-P update: 0 = automatic, 16, 24, 32 (used where it fits the LDS)
  *   VIEKF_TUNE_STREAM_MFMA   0 = the streaming kernels without matrix-core passes (one pass over P per measurement), 1 = with
  *                            them (default), 2 = with them but the propagate in r02's form (operands staged in global scratch)
+ *   VIEKF_TUNE_PANEL_SERVICE 0 = the grouped wide-P update with the measurement chain on every thread (r01-r03), 1 (default) = with a
+ *                            service wave running it ahead of the others (k_update_feat_panelsvc)
  *   VIEKF_TUNE_TILES         the tile family of the fused step (P as fp64-MFMA accumulator tiles, N = 46..50): 0 / 1 = not used
  *                            (the default: the resident family measures faster on the MI355X at every batch size), 2 = its
  *                            one-filter-per-workgroup form, 3 = its paired form (two filters per workgroup) */
 typedef enum viekf_tuning {
-  VIEKF_TUNE_RES_INSTANCE = 1, VIEKF_TUNE_UNIT_LAMBDA = 2, VIEKF_TUNE_BLOCK_GROUP = 3, VIEKF_TUNE_STREAM_MFMA = 4, VIEKF_TUNE_TILES = 5
+  VIEKF_TUNE_RES_INSTANCE = 1, VIEKF_TUNE_UNIT_LAMBDA = 2, VIEKF_TUNE_BLOCK_GROUP = 3, VIEKF_TUNE_STREAM_MFMA = 4, VIEKF_TUNE_TILES = 5,
+  VIEKF_TUNE_PANEL_SERVICE = 6
 } viekf_tuning;
 int viekf_batch_set_tuning(viekf_batch *b, int32_t key, int32_t value);
 /* which kernels a feature-update step of this batch launches, as text (for logs and benchmark records; no reference

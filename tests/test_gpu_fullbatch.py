@@ -124,129 +124,25 @@ def test_general_lambda_instances_full_batch(N):
     assert " ZU" not in g.describe()
 
 
-@pytest.mark.parametrize("N,group", [(85, 0), (85, 16), (85, 24), (100, 0), (100, 16), (90, 24)])
+@pytest.mark.parametrize("N,group", [(85, 0), (85, 16), (85, 24), (100, 0), (100, 16), (90, 24), (85, -1), (100, -1), (160, 0)])
 def test_wide_p_group_sizes(N, group):
-    """the grouped update's 24- and 32-measurement instances (chosen on their own for n > 256 where the panel fits: N = 85 ->
-    32, N = 100 -> 24) and forced group sizes, more measurements than one group: x, P (whole, mirrored from the lower
-    triangle) and codes against the oracle, P == P^T bit for bit (those instances had no parity case)"""
+    """the grouped update at the sizes between the families: the look-ahead kernel (groups of 16, the default where its LDS layout
+    fits: N <= 154), r03's kernel with forced group sizes 24 / 32 and with its own choice (group = -1: VIEKF_TUNE_PANEL_SERVICE = 0
+    -> 32 at N = 85, 24 at N = 100), N = 160 where only r03's kernel fits; more measurements than one group: x, P (whole, mirrored
+    from the lower triangle) and codes against the oracle, P == P^T bit for bit"""
     from vi_ekf_amd import capi
-    g = run_full(64, N, 2, [0, 31, 63], tune=[(capi.TUNE_BLOCK_GROUP, group)] if group else ())
+    tune = []
+    if group > 0:
+        tune.append((capi.TUNE_BLOCK_GROUP, group))
+    if group < 0:
+        tune.append((capi.TUNE_PANEL_SERVICE, 0))
+    g = run_full(64, N, 2, [0, 31, 63], tune=tune)
     d = g.describe()
-    assert "k_update_feat_blocked<512,%d>" % (group if group else (32 if N == 85 else 24)) in d, d
-
-
-# ---- the OTHER routes bench.py times, at the size it times them (VERDICT r03 "weak" #2): the multi-propagate instance of the
-# headline kernel (viekf_batch_step_n / _propagate_n_to) and the out-of-place ring store (P_out != P), B = 1024, N = 50, filters
-# of every dispatch round against the ORACLE (K vo_propagate calls + the updates; reference vi_ekf.cpp:262-318,
-# vi_ekf_meas.cpp:196-278), not against another HIP route.
-HEADLINE_SAMPLE = [0, 255, 256, 511, 700, 1023]
-
-
-def _headline_batch(steps, seed):
-    B, N = 1024, 50
-    sc = scene.make_scene(B, N, steps, seed=seed)
-    g = v.BatchVIEKF(B, N, sc["params"])
-    for i in range(N):
-        assert (g.init_feature(sc["pix"][:, i, :].copy(), np.full(B, np.nan)) == 1).all()
-    assert g.describe().startswith("k_step_resident<7,3>"), g.describe()
-    return sc, g
-
-
-def _oracle_filters(sc, N, which):
-    fs = []
-    for b in which:
-        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
-        for i in range(N):
-            f.init_feature(sc["pix"][b, i], i, float("nan"))
-        fs.append(f)
-    return fs
-
-
-def _check_sample(g, fs, which, what):
-    x, P = g.get_state(), g.get_covariance()
-    assert_close(x[which], np.stack([f.x for f in fs]), "x, " + what)
-    assert_close(P[which], np.stack([f.P for f in fs]), "P, " + what)
-    assert (g.get_status() & (1 | 2 | 8) == 0).all()
-    assert np.isfinite(x).all() and np.isfinite(P).all()
-    assert (P == P.transpose(0, 2, 1)).all(), "P != P^T somewhere in the batch, " + what
-
-
-@pytest.mark.parametrize("K", [8, 9])
-def test_step_n_headline_batch_vs_oracle(K):
-    """viekf_batch_step_n (cadence_250_30.fused in bench.py): K IMU samples + the frame's 50 updates in ONE launch of the
-    multi-propagate instance k_step_resident<7,3,MP>, two frames in a row, with uneven dt"""
-    which = np.asarray(HEADLINE_SAMPLE)
-    sc, g = _headline_batch(2 * K, 7100 + K)
-    fs = _oracle_filters(sc, 50, which)
-    dt = np.tile(sc["dt"], (K, 1)) * np.linspace(0.8, 1.2, K)[:, None]
-    for fr in range(2):
-        u = np.ascontiguousarray(sc["u"][fr * K:(fr + 1) * K])
-        res = g.step_n(u, dt, sc["z"][fr], sc["slot"], sc["R"])
-        for j, b in enumerate(which):
-            for k in range(K - 1):
-                fs[j].propagate(u[k, b], dt[k, b])
-            ref = fs[j].run_steps(u[K - 1, b][None], dt[K - 1, b], sc["z"][fr, b][None], sc["slot"][b], sc["R"])[0]
-            assert (res[b] == ref).all(), "meas_result codes differ (filter %d, frame %d)" % (b, fr)
-    _check_sample(g, fs, which, "step_n K=%d" % K)
-
-
-def test_propagate_n_to_headline_batch_vs_oracle():
-    """viekf_batch_propagate_n_to (the sequencer's closing replay): K = 8 propagates into ring slots 1..8 in one launch of the
-    same instance, only the last slot written; then select + get_state, then the frame's updates IN that slot"""
-    import ctypes as C
-    from vi_ekf_amd import capi
-    K = 8
-    which = np.asarray(HEADLINE_SAMPLE)
-    sc, g = _headline_batch(K, 7200)
-    fs = _oracle_filters(sc, 50, which)
-    L = capi.lib()
-    g.history_resize(K + 2)
-    g.snapshot(0)
-    capi.check(L.viekf_batch_select(g._h, 0))
-    u = np.ascontiguousarray(sc["u"][:K])
-    dt = np.ascontiguousarray(np.tile(sc["dt"], (K, 1)) * (1.0 + 0.05 * np.arange(K))[:, None])
-    slots = np.arange(1, K + 1, dtype=np.int32)
-    written = C.c_int32(-1)
-    p = lambda a: C.c_void_p(a.ctypes.data)
-    capi.check(L.viekf_batch_propagate_n_to(g._h, K, p(u), p(dt), p(slots), C.byref(written), capi.HOST))
-    assert written.value == 0
-    for j, b in enumerate(which):
-        for k in range(K):
-            fs[j].propagate(u[k, b], dt[k, b])
-    _check_sample(g, fs, which, "propagate_n_to K=8, slot 8")
-    res = g.update_feat(sc["z"][0], sc["slot"], sc["R"])
-    for j, b in enumerate(which):
-        for m in range(50):
-            r = fs[j].update(orc.FEAT, sc["z"][0, b, m], sc["R"], True, int(sc["slot"][b, m]))
-            assert r == res[b, m]
-    _check_sample(g, fs, which, "updates in ring slot 8")
-    g.history_resize(0)
-    _check_sample(g, fs, which, "after leaving the ring")
-
-
-def test_propagate_to_ring_slot_headline_batch_vs_oracle():
-    """viekf_batch_propagate_to: the out-of-place store of the fused kernel (P read from slot i, written to slot i + 1,
-    viekf_resident_worker.hpp: P_out != P) through three slots at B = 1024, N = 50; the slot left behind still holds its state"""
-    import ctypes as C
-    from vi_ekf_amd import capi
-    which = np.asarray(HEADLINE_SAMPLE)
-    sc, g = _headline_batch(3, 7300)
-    fs = _oracle_filters(sc, 50, which)
-    L = capi.lib()
-    g.history_resize(4)
-    g.snapshot(0)
-    capi.check(L.viekf_batch_select(g._h, 0))
-    p = lambda a: C.c_void_p(a.ctypes.data)
-    dt = np.ascontiguousarray(sc["dt"])
-    kept = None
-    for k in range(3):
-        u = np.ascontiguousarray(sc["u"][k])
-        capi.check(L.viekf_batch_propagate_to(g._h, p(u), p(dt), k + 1, capi.HOST))
-        for j, b in enumerate(which):
-            fs[j].propagate(u[b], dt[b])
-        _check_sample(g, fs, which, "propagate_to slot %d" % (k + 1))
-        if k == 0:
-            kept = (np.stack([f.x.copy() for f in fs]), np.stack([f.P.copy() for f in fs]))
-    capi.check(L.viekf_batch_select(g._h, 1))       # rewind: slot 1 was read by the second call, never written again
-    assert_close(g.get_state()[which], kept[0], "x of slot 1 after two more propagates")
-    assert_close(g.get_covariance()[which], kept[1], "P of slot 1 after two more propagates")
+    if group in (0, 16) and N <= 154:
+        assert "k_update_feat_panelsvc<512,16>" in d, d
+    elif group > 0:
+        assert "k_update_feat_blocked<512,%d>" % group in d, d
+    elif N == 160:
+        assert "k_update_feat_blocked<512,16>" in d, d
+    else:
+        assert "k_update_feat_blocked<512,%d>" % (32 if N == 85 else 24) in d, d

@@ -300,7 +300,8 @@ def test_device_pointer_path_matches_host_path():
     assert np.array_equal(g1.get_covariance(), g2.get_covariance())
 
 
-@pytest.mark.parametrize("N,M,prop", [(64, 4, 1), (150, 3, 1), (51, 51, 1), (150, 40, 1), (160, 35, 1), (160, 160, 1), (150, 40, 2), (64, 4, 2)])
+@pytest.mark.parametrize("N,M,prop", [(64, 4, 1), (150, 3, 1), (51, 51, 1), (150, 40, 1), (160, 35, 1), (160, 160, 1), (150, 40, 2), (64, 4, 2),
+                                      (150, 40, -1), (160, 160, -1), (51, 51, -1)])
 def test_wide_p_streaming_family(N, M, prop):
     """wide covariance (BASELINE config 5: N=150, n=466): the streaming family -- a few updates per step, and enough of them
     for full 16-measurement groups plus a partial one (N=160 is the ABI limit: whole 48-row super-tiles in the propagate,
@@ -318,6 +319,12 @@ def test_wide_p_streaming_family(N, M, prop):
         fs.append(f)
     g = make_gpu(sc, B, N, kernel=1)     # (N <= 77 would otherwise run on chip)
     from vi_ekf_amd import capi
+    if prop < 0:   # r03's grouped update, the measurement chain on every thread (VIEKF_TUNE_PANEL_SERVICE = 0, kept for A/B runs)
+        g.set_tuning(capi.TUNE_PANEL_SERVICE, 0)
+        prop = 1
+        assert "k_update_feat_blocked" in g.describe(), g.describe()
+    else:   # (the look-ahead kernel where its LDS layout fits: N <= 154)
+        assert ("k_update_feat_panelsvc" if N <= 154 else "k_update_feat_blocked") in g.describe(), g.describe()
     g.set_tuning(capi.TUNE_STREAM_MFMA, prop)
     assert ("k_propagate_wide" in g.describe()) == (prop == 1), g.describe()
     for s in range(steps):
@@ -419,3 +426,37 @@ def test_large_corrections(kernel, off):
     assert moved > 0.02 * off / 60.0                   # the correction really is large
     assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
+
+
+@pytest.mark.parametrize("N,f_bad", [(40, 7), (150, 20), (150, 3)])
+def test_wide_p_nan_guard_inside_a_group(N, f_bad):
+    """the NaN guard of an update (vi_ekf_meas.cpp:247) INSIDE a group of the look-ahead kernel: a NaN in the zeta column of one
+    feature makes that feature's K NaN on one row -- its update is skipped (fix_depth still runs, :271), the others run.  The service
+    wave cannot know (the verdict needs every row): the row phase finds out, nothing has been committed, the group is redone one
+    measurement at a time.  Compared with r03's kernel, which decides measurement by measurement (same codes, same NaN pattern, same
+    numbers to rounding); the dense oracle is no guide here -- a dense P H^T turns ANY NaN in a row of P into a NaN gain for every
+    measurement (0 x NaN), the block-sparse product of both kernels only when the measured feature's own column holds it."""
+    from vi_ekf_amd import capi
+    B = 3
+    sc = scene.make_scene(B, N, 1, seed=900 + N)
+    out = []
+    for svc in (1, 0):
+        g = make_gpu(sc, B, N, kernel=1)
+        g.set_tuning(capi.TUNE_PANEL_SERVICE, svc)
+        assert ("k_update_feat_panelsvc" if svc else "k_update_feat_blocked") in g.describe(), g.describe()
+        g.propagate(sc["u"][0], sc["dt"])
+        P = g.get_covariance()
+        c = 16 + 3 * f_bad
+        P[1, 5, c] = P[1, c, 5] = np.nan                  # filter 1 only: body row 5 x the first bearing column of feature f_bad
+        g.set_state(P=P)
+        res = g.update_feat(sc["z"][0], sc["slot"], sc["R"])
+        out.append((res.copy(), g.get_state(), g.get_covariance(), g.get_status()))
+    (ra, xa, Pa, sa), (rb, xb, Pb, sb) = out
+    assert (ra == rb).all() and (ra == 0).all()            # (a NaN-guarded update reports success, like the reference)
+    assert (sa == sb).all()
+    assert (np.isnan(Pa) == np.isnan(Pb)).all() and (np.isnan(xa) == np.isnan(xb)).all()
+    assert np.isnan(Pa[1]).any() and not np.isnan(Pa[0]).any() and not np.isnan(Pa[2]).any()
+    fin = ~np.isnan(Pb)
+    assert np.abs(Pa[fin] - Pb[fin]).max() <= 1e-9 * np.abs(Pb[fin]).max()
+    dx_ = np.abs(xa - xb)
+    assert dx_.max() <= 1e-9 * np.abs(xb).max(), (np.argwhere(dx_ > 1e-10)[:12].tolist(), dx_.max())

@@ -26,6 +26,9 @@ def main():
         g.set_tuning(capi.TUNE_TILES, 0)
     elif kernel:
         g.set_kernel(kernel)
+    for kv in sys.argv[5:]:         # KEY=VALUE pairs for viekf_batch_set_tuning
+        key, value = kv.split("=")
+        g.set_tuning(int(key), int(value))
     print(g.describe())
     g.use_torch_stream()
     d = {k: torch.tensor(sc[k], device=dev) for k in ("u", "z", "dt", "slot", "R")}
@@ -50,7 +53,7 @@ def main():
         return ms
 
     timeit(lambda: g.propagate(d["u"][0], d["dt"]), "propagate")
-    for M in (1, 2, 10, 25, N):
+    for M in (1, 2, 6, 10, 16, 25, N):
         timeit(lambda: g.update_feat(d["z"][0][:, :M].contiguous(), d["slot"][:, :M].contiguous(), d["R"],
                                      result=res[:, :M].contiguous()), "update_feat M=%d" % M)
     timeit(lambda: g.step(d["u"][0], d["dt"], d["z"][0], d["slot"], d["R"], result=res), "step")

@@ -14,7 +14,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_YAML, ERR_UNSUPPORTED = 0, -1, -2, 
 HOST, DEVICE = 0, 1
 MEAS_SKIPPED, MEAS_SUCCESS, MEAS_GATED, MEAS_NAN, MEAS_INVALID, MEAS_NEW_FEATURE = -1, 0, 1, 2, 3, 4
 FLAG_NAN, FLAG_BLOWING_UP, FLAG_NEGATIVE_DEPTH, FLAG_INTERNAL = 1, 2, 4, 8
-TUNE_RES_INSTANCE, TUNE_UNIT_LAMBDA, TUNE_BLOCK_GROUP, TUNE_STREAM_MFMA, TUNE_TILES = 1, 2, 3, 4, 5
+TUNE_RES_INSTANCE, TUNE_UNIT_LAMBDA, TUNE_BLOCK_GROUP, TUNE_STREAM_MFMA, TUNE_TILES, TUNE_PANEL_SERVICE = 1, 2, 3, 4, 5, 6
 
 # every symbol include/viekf.h declares (tests check the library exports exactly these)
 SYMBOLS = [

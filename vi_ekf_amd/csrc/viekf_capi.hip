@@ -107,6 +107,7 @@ struct viekf_batch {
   int tune_unit_lambda = 1;    // 0: never the unit-Lambda instances
   int tune_block_group = 0;    // 16 / 24 / 32: group size of the grouped update where its panel fits
   int tune_stream_mfma = 1;    // 0: the streaming kernels without matrix-core passes
+  int tune_panel_svc = 1;      // 0: the grouped update without the service wave (k_update_feat_blocked)
 };
 
 namespace {
@@ -254,8 +255,20 @@ int launch_propagate(viekf_batch* b, const double* d_u, const double* d_dt) {
 // over P for the narrower filters); 0 = the grouped kernel does not apply (then one pass per measurement).
 // (measured: at N = 64 groups of 32 are SLOWER than 16 -- 1.96 vs 1.83 ms per step, the sequential panel phase grows with the
 //  group -- while N = 100 gains 4 % from 24: the wider groups only where the passes dominate)
+// the look-ahead form of the grouped update (k_update_feat_panelsvc): groups of 16 -- the 48 rows of a group's features fit the
+// serving wave -- where its double-buffered LDS layout fits next to the panel (N <= 154 at groups of 16)
+bool panel_svc(const viekf_batch* b) {
+  if (b->tune_panel_svc == 0 || !(b->tune_block_group == 0 || b->tune_block_group == 16) || b->n > 512) return false;
+  const PsvLds PL(b->N, b->n, b->nxs, 16);
+  return sizeof(double) * (size_t)PL.total + 1024 <= 160 * 1024;
+}
+
 int blocked_group(const viekf_batch* b, size_t* lds_bytes) {
   if (!stream_mfma_ok(b) || b->n > 512) return 0;
+  if (panel_svc(b)) {
+    if (lds_bytes) *lds_bytes = sizeof(double) * (size_t)PsvLds(b->N, b->n, b->nxs, 16).total;
+    return 16;
+  }
   auto fits = [&](int cand, size_t* bytes) {
     const BlkLds BL(b->N, b->n, b->nxs, cand);
     *bytes = sizeof(double) * (size_t)BL.total;
@@ -281,11 +294,13 @@ int launch_update(viekf_batch* b, const double* d_z, const int* d_slot, int M, c
   const int bg = blocked_group(b, &blds);
   if (M >= 1 && bg > 0) {   // (a single measurement too: a group of one, no mirror pass before it)
     typedef void (*blk_kernel_t)(StreamArgs, const double*, const int*, int, const double*, long, long, int*);
-    const blk_kernel_t kern = bg == 32 ? k_update_feat_blocked<512, 32> : (bg == 24 ? k_update_feat_blocked<512, 24> : k_update_feat_blocked<512, 16>);
+    const bool sv = panel_svc(b);
+    const blk_kernel_t kern = sv ? k_update_feat_panelsvc<512, 16>
+                                 : (bg == 32 ? k_update_feat_blocked<512, 32> : (bg == 24 ? k_update_feat_blocked<512, 24> : k_update_feat_blocked<512, 16>));
     {
       std::lock_guard<std::mutex> lk(g_attr_mutex);
-      static size_t attr_bytes[64][3] = {};
-      size_t& have = attr_bytes[b->device & 63][bg == 32 ? 2 : (bg == 24 ? 1 : 0)];
+      static size_t attr_bytes[64][6] = {};
+      size_t& have = attr_bytes[b->device & 63][(bg == 32 ? 2 : (bg == 24 ? 1 : 0)) + (sv ? 3 : 0)];
       if (blds > have) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
         have = blds;
@@ -897,8 +912,9 @@ int viekf_batch_describe(const viekf_batch* b, char* out, int32_t cap) {
   } else {
     const int bg = blocked_group(b, nullptr);
     if (bg > 0)
-      snprintf(buf, sizeof buf, "%s + k_update_feat_blocked<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
-               "passes, lower triangle only)", (b->tune_stream_mfma != 2 && 3 * b->N <= 512) ? "k_propagate_wide (K = 24 records in LDS)" : "k_propagate_stream", bg, bg);
+      snprintf(buf, sizeof buf, "%s + %s<512,%d> (P in HBM/L2, one pass per group of %d measurements, fp64 MFMA "
+               "passes, lower triangle only)", (b->tune_stream_mfma != 2 && 3 * b->N <= 512) ? "k_propagate_wide (K = 24 records in LDS)" : "k_propagate_stream",
+               panel_svc(b) ? "k_update_feat_panelsvc" : "k_update_feat_blocked", bg, bg);
     else
       snprintf(buf, sizeof buf, "k_propagate_stream + k_update_feat_stream (P in HBM/L2, one pass per measurement)");
   }
@@ -962,6 +978,9 @@ int viekf_batch_set_tuning(viekf_batch* b, int32_t key, int32_t value) {
     case VIEKF_TUNE_BLOCK_GROUP:
       if (value != 0 && value != 16 && value != 24 && value != 32) return fail(VIEKF_ERR_INVALID, "group size must be 0 (auto), 16, 24 or 32");
       b->tune_block_group = value;
+      return VIEKF_OK;
+    case VIEKF_TUNE_PANEL_SERVICE:
+      b->tune_panel_svc = value != 0;
       return VIEKF_OK;
     case VIEKF_TUNE_TILES:
       if (value < 0 || value > 3) return fail(VIEKF_ERR_INVALID, "tile family: 0 off, 1 automatic, 2 single form, 3 paired form");

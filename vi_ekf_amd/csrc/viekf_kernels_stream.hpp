@@ -582,6 +582,111 @@ __global__ __launch_bounds__(T) void k_update_feat_stream(StreamArgs a, const do
 // keeping W alone (K costs two multiply-adds per operand instead of 127 KB of LDS) is what lets BG = 16 fit at N = 160.
 // LDS rows of W are 34 doubles apart: the MFMA operand reads (16 consecutive rows per k) then spread over the banks.
 // ------------------------------------------------------------------------------------------------
+// One pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores.
+//      D[r][c] = sum_k W[j0+r][k] K[i0+c][k]:  D's column index (lane & 15) runs along the ROWS of P (contiguous in memory).
+// (shared by the two grouped update kernels: k_update_feat_blocked below and k_update_feat_panelsvc in viekf_kernels_wide.hpp)
+// ticket != NULL: the units are drawn from a counter in LDS instead of being dealt round-robin (waves that arrive late -- they had
+// other work first -- then simply take fewer)
+template <int T, int BLD>
+__device__ __forceinline__ void blk_pass(double* __restrict__ P, int ld, int nact, int Gn, const double* Wp, const double* SiL,
+                                         const double* lam, const double* diag, bool partial, int lane, int wave, int* ticket = nullptr) {
+  constexpr int NWV = T / 64;
+    const int nt = (nact + 15) >> 4;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
+    constexpr int TPI = 8;   // tiles per wave and unit: their 32 loads of P are in flight together (one tile at a time
+                             // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
+    // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a diagonal
+    // tile forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
+    // Work unit of a wave: TPI vertically adjacent tiles of one column block (rows 16 ti0 .. +127): its loads cover 1024
+    // contiguous bytes per column (HBM likes long runs: 128-byte runs scattered over the matrix reached 2.8 TB/s).  Units
+    // are numbered column block by column block over the lower triangle and dealt to the waves round-robin.
+    struct Unit { int tj, ti0; };
+    auto next_unit = [&](Unit u, int steps) {            // advance `steps` units (past the end: tj == nt)
+      for (int s2 = 0; s2 < steps && u.tj < nt; s2++) {
+        u.ti0 += TPI;
+        if (u.ti0 >= nt) { u.tj++; u.ti0 = u.tj; }
+      }
+      return u;
+    };
+    auto load_tiles = [&](Unit u, double (&pq)[TPI][4]) {
+      const int tj = min(u.tj, nt - 1);                  // (clamped, unconditional loads: branch-free, so the compiler can
+#pragma unroll                                             //  count them exactly instead of draining the queue at every use)
+      for (int q = 0; q < TPI; q++) {
+        const int i = min(16 * (u.ti0 + q) + lr, nact - 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int j = min(16 * tj + lk + 4 * rg, nact - 1);
+          pq[q][rg] = P[i + (long)j * ld];
+        }
+      }
+    };
+    auto draw = [&]() {                                  // the unit of the next ticket (wave-uniform)
+      int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1);
+      return next_unit(Unit{0, 0}, __builtin_amdgcn_readfirstlane(t));
+    };
+    double pv[TPI][4];
+    Unit u = ticket ? draw() : next_unit(Unit{0, 0}, wave);
+    while (u.tj < nt) {
+      load_tiles(u, pv);                // (the SIMD's other wave computes meanwhile; an explicit prefetch of the next unit
+      const Unit un = ticket ? draw() : next_unit(u, NWV);   //  did not pay for its registers)
+      const int tj = u.tj, j0t = 16 * tj;
+#pragma unroll
+      for (int q = 0; q < TPI; q++) {
+        const int ti = u.ti0 + q;
+        if (ti >= nt) break;
+        const int i0 = 16 * ti;
+        const bool diag_t = ti == tj;
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int sk = 0; sk < ksteps; sk++) {
+          const int c = 4 * sk + lk;                       // this lane's contraction index: column c of pair c >> 1
+          const double wjc = Wp[(j0t + lr) * BLD + c];
+          const double2 wi = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
+          const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+          const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c], the same expression as in the panel phase
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc, 0, 0, 0);                          // K_i . W_j
+          if (diag_t) {                                    // (wave-uniform)
+            const double2 wj = *reinterpret_cast<const double2*>(Wp + (j0t + lr) * BLD + (c & ~1));
+            const double wic = (c & 1) ? wi.y : wi.x;
+            const double kjc = wj.x * sv.x + wj.y * sv.y;
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kjc, wic, acc2, 0, 0, 0);                      // K_j . W_i
+          }
+        }
+        if (diag_t) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+            if (i0 + lr < j0t + lk + 4 * rg) acc[rg] = acc2[rg];   // upper triangle of the diagonal tile
+        }
+        const int i = i0 + lr;
+        const double li = lam[min(i, nact - 1)];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {                   // (results stay in pv: every store is issued after the last
+          const int j = j0t + lk + 4 * rg;                 //  wait on a load -- a store ahead of a load wait would be waited for too)
+          const double lj = lam[min(j, nact - 1)];
+          const double Lij = partial ? (lj + li - li * lj) : 1.0;
+          double v = pv[q][rg] - Lij * acc[rg];
+          if (i == j && i >= 16 && i < nact && (i - 16) % 3 == 2) v = diag[(i - 16) / 3];
+          pv[q][rg] = v;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < TPI; q++) {
+        const int ti = u.ti0 + q;
+        const int i = 16 * ti + lr;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int j = 16 * tj + lk + 4 * rg;
+          if (ti < nt && i < nact && j < nact) {
+            P[i + (long)j * ld] = pv[q][rg];   // (no mirror store: nothing reads above the diagonal, see the panel load)
+          }
+        }
+      }
+      u = un;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // BG = measurements per group (template parameter: 16, 24 or 32 -- the largest whose panel fits the LDS, so that the narrower
 // filters of this family cross HBM fewer times); BLD = 2 BG + 2 = LDS row stride (doubles) of the n x 2 BG panel; BWIN = 2 BG
 // measurement-list entries staged per group
@@ -860,98 +965,8 @@ __global__ __launch_bounds__(T) void k_update_feat_blocked(StreamArgs a, const d
       if (res && tid == 0) *res = 0;
       __syncthreads();                                     // barrier 2: state, panel and pzz are ready for the next measurement
     }
-    // ---- 3. one pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores.
-    //      D[r][c] = sum_k W[j0+r][k] K[i0+c][k]:  D's column index (lane & 15) runs along the ROWS of P (contiguous in memory).
-    {
-      const int nt = (nact + 15) >> 4;
-      const int lr = lane & 15, lk = lane >> 4;
-      const int ksteps = (2 * Gn + 3) >> 2;               // (columns past 2 Gn are zero)
-      constexpr int TPI = 8;   // tiles per wave and unit: their 32 loads of P are in flight together (one tile at a time
-                               // leaves 2 KB per wave on the wire and the pass latency-bound at a fraction of the HBM rate)
-      // P stays EXACTLY symmetric and is read only once per pair: the tiles on and below the diagonal are processed; a diagonal
-      // tile forms K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j.
-      // Work unit of a wave: TPI vertically adjacent tiles of one column block (rows 16 ti0 .. +127): its loads cover 1024
-      // contiguous bytes per column (HBM likes long runs: 128-byte runs scattered over the matrix reached 2.8 TB/s).  Units
-      // are numbered column block by column block over the lower triangle and dealt to the waves round-robin.
-      struct Unit { int tj, ti0; };
-      auto next_unit = [&](Unit u, int steps) {            // advance `steps` units (past the end: tj == nt)
-        for (int s2 = 0; s2 < steps && u.tj < nt; s2++) {
-          u.ti0 += TPI;
-          if (u.ti0 >= nt) { u.tj++; u.ti0 = u.tj; }
-        }
-        return u;
-      };
-      auto load_tiles = [&](Unit u, double (&pq)[TPI][4]) {
-        const int tj = min(u.tj, nt - 1);                  // (clamped, unconditional loads: branch-free, so the compiler can
-#pragma unroll                                             //  count them exactly instead of draining the queue at every use)
-        for (int q = 0; q < TPI; q++) {
-          const int i = min(16 * (u.ti0 + q) + lr, nact - 1);
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int j = min(16 * tj + lk + 4 * rg, nact - 1);
-            pq[q][rg] = P[i + (long)j * ld];
-          }
-        }
-      };
-      double pv[TPI][4];
-      Unit u = next_unit(Unit{0, 0}, wave);
-      while (u.tj < nt) {
-        load_tiles(u, pv);                // (the SIMD's other wave computes meanwhile; an explicit prefetch of the next unit
-        const Unit un = next_unit(u, NWV);   //  did not pay for its registers)
-        const int tj = u.tj, j0t = 16 * tj;
-#pragma unroll
-        for (int q = 0; q < TPI; q++) {
-          const int ti = u.ti0 + q;
-          if (ti >= nt) break;
-          const int i0 = 16 * ti;
-          const bool diag_t = ti == tj;
-          v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-          for (int sk = 0; sk < ksteps; sk++) {
-            const int c = 4 * sk + lk;                       // this lane's contraction index: column c of pair c >> 1
-            const double wjc = Wp[(j0t + lr) * BLD + c];
-            const double2 wi = *reinterpret_cast<const double2*>(Wp + (i0 + lr) * BLD + (c & ~1));
-            const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
-            const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c], the same expression as in the panel phase
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc, 0, 0, 0);                          // K_i . W_j
-            if (diag_t) {                                    // (wave-uniform)
-              const double2 wj = *reinterpret_cast<const double2*>(Wp + (j0t + lr) * BLD + (c & ~1));
-              const double wic = (c & 1) ? wi.y : wi.x;
-              const double kjc = wj.x * sv.x + wj.y * sv.y;
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kjc, wic, acc2, 0, 0, 0);                      // K_j . W_i
-            }
-          }
-          if (diag_t) {
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++)
-              if (i0 + lr < j0t + lk + 4 * rg) acc[rg] = acc2[rg];   // upper triangle of the diagonal tile
-          }
-          const int i = i0 + lr;
-          const double li = lam[min(i, nact - 1)];
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {                   // (results stay in pv: every store is issued after the last
-            const int j = j0t + lk + 4 * rg;                 //  wait on a load -- a store ahead of a load wait would be waited for too)
-            const double lj = lam[min(j, nact - 1)];
-            const double Lij = partial ? (lj + li - li * lj) : 1.0;
-            double v = pv[q][rg] - Lij * acc[rg];
-            if (i == j && i >= 16 && i < nact && (i - 16) % 3 == 2) v = diag[(i - 16) / 3];
-            pv[q][rg] = v;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < TPI; q++) {
-          const int ti = u.ti0 + q;
-          const int i = 16 * ti + lr;
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const int j = 16 * tj + lk + 4 * rg;
-            if (ti < nt && i < nact && j < nact) {
-              P[i + (long)j * ld] = pv[q][rg];   // (no mirror store: nothing reads above the diagonal, see the panel load)
-            }
-          }
-        }
-        u = un;
-      }
-    }
+    // ---- 3. one pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores (blk_pass above)
+    blk_pass<T, BLD>(P, ld, nact, Gn, Wp, SiL, lam, diag, partial, lane, wave);
     __syncthreads();
   }
   for (int i = tid; i < xZ + 5 * len; i += T) {
