@@ -97,6 +97,17 @@ __global__ __launch_bounds__((NW + NS) * 64, (NW <= 3) ? 2 : 1) void k_step_resi
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.B) return;
   if (a.active && !a.active[blockIdx.x]) return;   // (the whole workgroup: before any barrier)
+#ifdef VIEKF_ABLATE
+  {   // timing experiment (DESIGN.md 5.2, r04 xxxi): are the two workgroups of a CU better off OUT of step?  Half of the workgroups
+      // start late by ((bits >> 4) & 7) x 8 us; bit 7 picks which half: 0 = the odd ones, 1 = every second block of 256
+    const int bits = (do_prop >> 8) & 0xff, st = (bits >> 4) & 7;
+    const bool late = (bits & 128) ? ((blockIdx.x >> 8) & 1) != 0 : (blockIdx.x & 1) != 0;
+    if (st && late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)st * 19200ull) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+#endif
   ResShared S;
   res_prologue<T>(a, S, smem, do_prop, dt_all, z_all, slot_all, M, m_stride, R_all, r_stride_b, r_stride_m, result_all);
   // The service wave's chain is the floor of an update, so it should not share its SIMD's issue slots with a worker wave.  A
