@@ -396,6 +396,118 @@ __device__ __forceinline__ double psv_rl(double v, int src) {   // lane src's va
 }
 __device__ __forceinline__ int psv_tri(int g, int gp, int BG) { return g * BG - g * (g + 1) / 2 + (gp - g - 1); }   // g < gp
 
+// The pass of the look-ahead kernel:  P -= Lambda o (K W^T)  on the lower triangle, 16 x 16 tiles on the fp64 matrix cores, like
+// blk_pass (viekf_kernels_stream.hpp) -- but r04 measured that pass to be LATENCY-bound, not HBM-bound (B = 64 filters, a quarter of the
+// traffic and all of it cache-resident, take 1.66 ms per step against 1.76 ms at B = 256): a wave walks its tiles one by one, every
+// k-step a chain of three LDS reads -> K -> one MFMA into the same accumulator.  Here a wave works on FOUR tiles of a unit at a time: the
+// four accumulator chains are independent, and the W rows of the unit's column block and the S^-1 columns -- the same for every tile of
+// the unit -- are read once per k-step instead of once per tile and k-step (6 LDS reads per 4 MFMAs instead of 12).  The diagonal tiles
+// (both orientations, second accumulator) are units of their own and keep the one-tile form.  Units are drawn from an LDS counter.
+template <int T, int BLD>
+__device__ __forceinline__ void psv_pass(double* __restrict__ P, int ld, int nact, int Gn, const double* Wp, const double* SiL,
+                                         const double* lam, bool partial, int lane, int* ticket) {
+  const int nt = (nact + 15) >> 4;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ksteps = (2 * Gn + 3) >> 2;                   // (columns past 2 Gn are zero)
+  constexpr int TPI = 8;                                  // tiles per unit: 8 vertically adjacent ones (1 KB contiguous per column)
+  auto draw = [&]() {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  for (int t = draw();; t = draw()) {
+    if (t < nt) {
+      // ---- a diagonal tile: K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j
+      const int j0t = 16 * t, i = j0t + lr;
+      double pv[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) pv[rg] = P[min(i, nact - 1) + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+      for (int sk = 0; sk < ksteps; sk++) {
+        const int c = 4 * sk + lk;
+        const double2 wi = *reinterpret_cast<const double2*>(Wp + i * BLD + (c & ~1));
+        const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+        const double wic = (c & 1) ? wi.y : wi.x;
+        const double kic = wi.x * sv.x + wi.y * sv.y;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wic, kic, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kic, wic, acc2, 0, 0, 0);
+      }
+      const double li = lam[min(i, nact - 1)];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int j = j0t + lk + 4 * rg;
+        const double lj = lam[min(j, nact - 1)];
+        const double Lij = partial ? (lj + li - li * lj) : 1.0;
+        const double av = (i < j) ? acc2[rg] : acc[rg];
+        if (i < nact && j < nact) P[i + (long)j * ld] = pv[rg] - Lij * av;
+      }
+      continue;
+    }
+    // ---- a unit strictly below the diagonal: column block tj, tiles ti0 .. ti0 + 7
+    int tj = 0, ti0 = 0;
+    {
+      int rest = t - nt;
+      for (; tj < nt; tj++) {
+        const int nu = (nt - 1 - tj + TPI - 1) / TPI;     // units of this column block (rows tj + 1 .. nt - 1)
+        if (rest < nu) break;
+        rest -= nu;
+      }
+      if (tj >= nt) break;                                // past the last unit: done
+      ti0 = tj + 1 + TPI * rest;
+    }
+    const int j0t = 16 * tj;
+    double pv[TPI][4];
+#pragma unroll
+    for (int q = 0; q < TPI; q++) {                       // (clamped, unconditional loads: the 32 of a unit in flight together)
+      const int i = min(16 * (ti0 + q) + lr, nact - 1);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) pv[q][rg] = P[i + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
+    }
+    double lj[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) lj[rg] = lam[min(j0t + lk + 4 * rg, nact - 1)];
+#pragma unroll
+    for (int h = 0; h < TPI; h += 4) {
+      if (ti0 + h >= nt) break;
+      v4f64 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+      int ib[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ib[q] = min(16 * (ti0 + h + q), 16 * (nt - 1)) + lr;   // (a tile past the end redoes the last one: discarded)
+      for (int sk = 0; sk < ksteps; sk++) {
+        const int c = 4 * sk + lk;                         // this lane's contraction index: column c of pair c >> 1
+        const double wjc = Wp[(j0t + lr) * BLD + c];
+        const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double2 wi = *reinterpret_cast<const double2*>(Wp + ib[q] * BLD + (c & ~1));
+          const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c]
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc[q], 0, 0, 0);   // K_i . W_j
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double li = lam[min(ib[q], nact - 1)];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const double Lij = partial ? (lj[rg] + li - li * lj[rg]) : 1.0;
+          pv[h + q][rg] -= Lij * acc[q][rg];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TPI; q++) {                       // (every store after the last wait on a load)
+      const int i = 16 * (ti0 + q) + lr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int j = j0t + lk + 4 * rg;
+        if (ti0 + q < nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
+      }
+    }
+  }
+}
+
 // Diagnostic build only (-DVIEKF_STAMPS, tools/stamps_wide.py): s_memtime stamps of filter 0, lane 0 of every wave, into the
 // workspace: [16 wave + idx], in the SECOND trip of the group loop (the first overlapped one)
 #ifdef VIEKF_STAMPS
@@ -561,6 +673,8 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
     // ================= S: the service wave runs cur's chain  ||  the others: prev's state corrections (D) and pass
     if (svc) {
       if (Gn > 0) {
+        // (the chain is ONE wave's serial work next to seven waves of pass: it gets the issue slots it asks for)
+        __builtin_amdgcn_s_setprio(3);
         double* mail = smem + L.mail + pb * L.mail_sz;
         double* ctab = smem + L.ctab + pb * L.ctab_sz;
         double* cbuf = smem + L.cbuf + pb * L.cbuf_sz;
@@ -708,6 +822,7 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
           double* cb = cbuf + 6 * sq_l;
           cb[0] = sq[0]; cb[1] = sq[1]; cb[2] = sq[2]; cb[3] = sq[3]; cb[4] = srho; cb[5] = sprr;
         }
+        __builtin_amdgcn_s_setprio(0);
       }
     } else if (Gp > 0) {
       // ---- D of prev: the features outside prev and cur (prev's are committed, cur's ride with the service wave) and the body,
@@ -761,10 +876,9 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
       PSV_STAMP(1);
     }
     PSV_STAMP(2);
-    // prev's pass over P:  P -= Lambda o (K W^T), 16 x 16 tiles on the fp64 matrix cores; the units are drawn from a counter, so the
-    // waves that come late (the three with feature lanes, the one with the body lane, the service wave) take what is left.  (The
-    // rho-rho entries the pass writes from `diag` may be a step behind while D runs: they are written again at the end of the launch.)
-    if (Gp > 0) blk_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, diag, partial, lane, wave, flg + 2);
+    // prev's pass over P (psv_pass above); the units are drawn from a counter, so the waves that come late (the three with feature
+    // lanes, the one with the body lane, the service wave) take what is left.  (The rho-rho diagonal is kept in LDS: written at the end.)
+    if (Gp > 0) psv_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, partial, lane, flg + 2);
     PSV_STAMP(6);
     __syncthreads();                                       // prev's pass is done; cur's mail / ctab / cbuf are ready
     PSV_STAMP(3);
