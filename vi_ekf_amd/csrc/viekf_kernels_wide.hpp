@@ -891,18 +891,14 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
 
     // ================= A: panel <- the zeta columns of cur's features from the lower triangle of P (one row per thread)
     for (int i = tid; i < nact; i += T) {
-#pragma unroll 1
-      for (int cc = 0; cc < NC; cc += 8) {                // eight independent column loads in flight per thread
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int c = cc + k;
-          const int col = 16 + 3 * gsl[(c < 2 * Gn) ? (c >> 1) : 0] + (c & 1);
-          v[k] = (c < 2 * Gn) ? P[max(i, col) + (long)min(i, col) * ld] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(Wp + i * BLD + cc + k) = make_double2(v[k], v[k + 1]);
+      double v[NC];                                        // (all 32 column loads of the row in flight: this phase is four memory
+#pragma unroll                                             //  latencies long with eight at a time, and nothing else runs beside it)
+      for (int c = 0; c < NC; c++) {
+        const int col = 16 + 3 * gsl[(c < 2 * Gn) ? (c >> 1) : 0] + (c & 1);
+        v[c] = (c < 2 * Gn) ? P[max(i, col) + (long)min(i, col) * ld] : 0.0;
       }
+#pragma unroll
+      for (int c = 0; c < NC; c += 2) *reinterpret_cast<double2*>(Wp + i * BLD + c) = make_double2(v[c], v[c + 1]);
     }
     if (tid < 4 * BG) SiL[tid] = 0.0;
     PSV_STAMP(4);
