@@ -244,9 +244,27 @@ def secondary_config(v, scene, torch, dev, dev_index, B, N, K, W, parity_steps, 
     out.update({"steps": K, "warmup": W, "ms_per_step": secs / K * 1e3, "steps_per_s": B * K / secs,
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "alg_bytes_per_step": b_alg * B, "traffic": traffic, "traffic_source": src},
+                "flops": flops_block(N, B * K / secs),
                 "bad_filters": int((st & (1 | 2 | 8) != 0).sum())})
     g.close()
     return out
+
+
+def flops_block(N, steps_per_s):
+    """Structured algorithmic flops of one step: Phi P Phi^T + G Q G^T + N rank-2 Lambda-masked sweeps, priced against
+    the part's fp64 peak (the secondary ceiling of SURVEY 8d: the fused step's intensity is above the fp64 ridge)."""
+    n_ = 16 + 3 * N
+    f_alg = 2 * 2 * n_ * (256 + 57 * N) + 12 * n_ * n_ + N * 6 * n_ * n_
+    # what the kernels EXECUTE: P is symmetric and one block / tile of every pair is held, so the sweeps and the
+    # propagate touch n (n + 1) / 2 elements -- roughly half the algorithmic count above, which prices the full matrix
+    f_exec = 2 * n_ * (256 + 57 * N) + 6 * n_ * n_ + N * 3 * n_ * (n_ + 1)
+    return {"alg_flop_per_step": f_alg, "achieved_tflops": f_alg * steps_per_s / 1e12, "peak_tflops": 78.6,
+            "frac": f_alg * steps_per_s / 1e12 / 78.6,
+            "executed_flop_per_step": f_exec, "executed_tflops": f_exec * steps_per_s / 1e12,
+            "executed_frac": f_exec * steps_per_s / 1e12 / 78.6,
+            "note": "frac prices the full n x n matrix (SURVEY 8d); the kernels hold and sweep the symmetric half: executed_frac is the pipe "
+                    "utilisation. Measured on this part (tools/micro): v_fma_f64 issues every 4.4-5.8 clk per SIMD, "
+                    "v_mfma_f64_16x16x4 every 64 clk = the same 16 FMA/clk/SIMD: the 78.6 TFLOP/s peak holds for both pipes"}
 
 
 def main():
@@ -597,19 +615,7 @@ def main():
             "timed_work": work,
             "reduction": rec,
         }
-        # structured algorithmic flops of one step: Phi P Phi^T + G Q G^T + N rank-2 Lambda-masked sweeps
-        n_ = 16 + 3 * N
-        f_alg = 2 * 2 * n_ * (256 + 57 * N) + 12 * n_ * n_ + N * 6 * n_ * n_
-        # what the on-chip kernels EXECUTE: P is symmetric and one block / tile of every pair is held, so the sweeps and the
-        # propagate touch n (n + 1) / 2 elements -- roughly half the algorithmic count above, which prices the full matrix
-        f_exec = 2 * n_ * (256 + 57 * N) + 6 * n_ * n_ + N * 3 * n_ * (n_ + 1)
-        out["flops"] = {"alg_flop_per_step": f_alg, "achieved_tflops": f_alg * B / launch_s / 1e12, "peak_tflops": 78.6,
-                        "frac": f_alg * B / launch_s / 1e12 / 78.6,
-                        "executed_flop_per_step": f_exec, "executed_tflops": f_exec * B / launch_s / 1e12,
-                        "executed_frac": f_exec * B / launch_s / 1e12 / 78.6,
-                        "note": "frac prices the full n x n matrix (SURVEY 8d); the kernels hold and sweep the symmetric half: executed_frac is the pipe "
-                             "utilisation. Measured on this part (tools/micro): v_fma_f64 issues every 4.4-5.8 clk per SIMD, "
-                             "v_mfma_f64_16x16x4 every 64 clk = the same 16 FMA/clk/SIMD: the 78.6 TFLOP/s peak holds for both pipes"}
+        out["flops"] = flops_block(N, B / launch_s)
         if cadence is not None:
             out["cadence_250_30"] = cadence
         if single is not None:
