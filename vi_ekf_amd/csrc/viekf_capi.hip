@@ -788,7 +788,15 @@ int viekf_batch_create(int32_t batch, int32_t num_features, const viekf_params* 
   b->nx = 17 + 5 * num_features;
   b->n = 16 + 3 * num_features;
   b->nxs = (b->nx + 1) & ~1;
-  b->ld = (b->n + 1) & ~1;
+  // Column stride of P.  The streaming family (N > 77: P crosses HBM several times per step) gets columns that start on whole 128-B
+  // lines, so that the 16 rows of a tile column are ONE line instead of parts of two: tools/micro/cu_stream_rate moves 6.4 instead
+  // of 5.2 TB/s with the wide-P pass's access pattern, the N = 150 step went from 5.66 to 5.3 ms.  The on-chip family reads and
+  // writes P once per launch and is 0.9 % SLOWER with padded columns at N = 50 (0.3495 against 0.3464 ms, three alternating runs
+  // of each on one box: 239 instead of 226 MB of P next to the 256 MiB Infinity Cache): it keeps the dense stride.
+  b->ld = num_features > 77 ? (b->n + 15) & ~15 : (b->n + 1) & ~1;
+#ifdef VIEKF_LD_PAD_ALL               // (diagnostic build, tools/build_variant.sh: A/B of the padded stride on the on-chip family)
+  b->ld = (b->n + 15) & ~15;
+#endif
   b->params = *p;
   DevParams& d = b->dp;
   std::memcpy(d.Qu, p->Qu, sizeof d.Qu);

@@ -405,105 +405,142 @@ __device__ __forceinline__ int psv_tri(int g, int gp, int BG) { return g * BG - 
 // (both orientations, second accumulator) are units of their own and keep the one-tile form.  Units are drawn from an LDS counter.
 template <int T, int BLD>
 __device__ __forceinline__ void psv_pass(double* __restrict__ P, int ld, int nact, int Gn, const double* Wp, const double* SiL,
-                                         const double* lam, bool partial, int lane, int* ticket) {
+                                         const double* lam, bool partial, int lane, int* ticket,
+                                         unsigned long long* st = nullptr) {
   const int nt = (nact + 15) >> 4;
   const int lr = lane & 15, lk = lane >> 4;
   const int ksteps = (2 * Gn + 3) >> 2;                   // (columns past 2 Gn are zero)
-  constexpr int TPI = 8;                                  // tiles per unit: 8 vertically adjacent ones (1 KB contiguous per column)
+#ifdef VIEKF_STAMPS
+  int sn = 0;                                             // diagnostic build: the first eight marks of this wave's pass
+#define PASS_STAMP()                                                                      \
+  do {                                                                                    \
+    if (st && sn < 8) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      if (lane == 0) st[sn] = __builtin_amdgcn_s_memtime();                               \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      sn++;                                                                               \
+    }                                                                                     \
+  } while (0)
+#else
+#define PASS_STAMP() do {} while (0)
+#endif
+  constexpr int TPI = 4;                                  // tiles per unit: 4 vertically adjacent ones (512 B contiguous per column)
+  int NU = 0;                                             // units strictly below the diagonal: tickets 0 .. NU - 1, then the nt diagonal tiles
+  for (int tj = 0; tj < nt; tj++) NU += (nt - 1 - tj + TPI - 1) / TPI;
   auto draw = [&]() {
     int t = 0;
     if (lane == 0) t = atomicAdd(ticket, 1);
     return __builtin_amdgcn_readfirstlane(t);
   };
-  for (int t = draw();; t = draw()) {
-    if (t < nt) {
-      // ---- a diagonal tile: K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j
-      const int j0t = 16 * t, i = j0t + lr;
-      double pv[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) pv[rg] = P[min(i, nact - 1) + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
-      v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-      for (int sk = 0; sk < ksteps; sk++) {
-        const int c = 4 * sk + lk;
-        const double2 wi = *reinterpret_cast<const double2*>(Wp + i * BLD + (c & ~1));
-        const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
-        const double wic = (c & 1) ? wi.y : wi.x;
-        const double kic = wi.x * sv.x + wi.y * sv.y;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wic, kic, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kic, wic, acc2, 0, 0, 0);
-      }
-      const double li = lam[min(i, nact - 1)];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int j = j0t + lk + 4 * rg;
-        const double lj = lam[min(j, nact - 1)];
-        const double Lij = partial ? (lj + li - li * lj) : 1.0;
-        const double av = (i < j) ? acc2[rg] : acc[rg];
-        if (i < nact && j < nact) P[i + (long)j * ld] = pv[rg] - Lij * av;
-      }
-      continue;
+  // ---- a unit strictly below the diagonal: column block tj, tiles ti0 .. ti0 + 7.  Software-pipelined over two register sets: the
+  // 32 loads of the NEXT unit are issued before the matrix-core work of the current one (a wave used to wait out the whole memory
+  // latency of its unit with nothing else to do: a quarter of its pass time)
+  auto issue = [&](int t, double (&pv)[TPI][4], double (&lj)[4], int& tj, int& ti0) {
+    int rest = t;
+    for (tj = 0; tj < nt; tj++) {
+      const int nu = (nt - 1 - tj + TPI - 1) / TPI;       // units of this column block (rows tj + 1 .. nt - 1)
+      if (rest < nu) break;
+      rest -= nu;
     }
-    // ---- a unit strictly below the diagonal: column block tj, tiles ti0 .. ti0 + 7
-    int tj = 0, ti0 = 0;
-    {
-      int rest = t - nt;
-      for (; tj < nt; tj++) {
-        const int nu = (nt - 1 - tj + TPI - 1) / TPI;     // units of this column block (rows tj + 1 .. nt - 1)
-        if (rest < nu) break;
-        rest -= nu;
-      }
-      if (tj >= nt) break;                                // past the last unit: done
-      ti0 = tj + 1 + TPI * rest;
-    }
+    ti0 = tj + 1 + TPI * rest;
     const int j0t = 16 * tj;
-    double pv[TPI][4];
 #pragma unroll
     for (int q = 0; q < TPI; q++) {                       // (clamped, unconditional loads: the 32 of a unit in flight together)
       const int i = min(16 * (ti0 + q) + lr, nact - 1);
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) pv[q][rg] = P[i + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
     }
-    double lj[4];
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) lj[rg] = lam[min(j0t + lk + 4 * rg, nact - 1)];
+  };
+  auto finish = [&](double (&pv)[TPI][4], const double (&lj)[4], int tj, int ti0) {
+    const int j0t = 16 * tj;
 #pragma unroll
     for (int h = 0; h < TPI; h += 4) {
-      if (ti0 + h >= nt) break;
-      v4f64 acc[4];
+      if (h == 0 || ti0 + h < nt) {                        // (the first four tiles of a unit always exist)
+        v4f64 acc[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
-      int ib[4];
+        for (int q = 0; q < 4; q++) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+        int ib[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) ib[q] = min(16 * (ti0 + h + q), 16 * (nt - 1)) + lr;   // (a tile past the end redoes the last one: discarded)
-      for (int sk = 0; sk < ksteps; sk++) {
-        const int c = 4 * sk + lk;                         // this lane's contraction index: column c of pair c >> 1
-        const double wjc = Wp[(j0t + lr) * BLD + c];
-        const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+        for (int q = 0; q < 4; q++) ib[q] = min(16 * (ti0 + h + q), 16 * (nt - 1)) + lr;   // (a tile past the end redoes the last one: discarded)
+        for (int sk = 0; sk < ksteps; sk++) {
+          const int c = 4 * sk + lk;                         // this lane's contraction index: column c of pair c >> 1
+          const double wjc = Wp[(j0t + lr) * BLD + c];
+          const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double2 wi = *reinterpret_cast<const double2*>(Wp + ib[q] * BLD + (c & ~1));
+            const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c]
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc[q], 0, 0, 0);   // K_i . W_j
+          }
+        }
+        PASS_STAMP();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const double2 wi = *reinterpret_cast<const double2*>(Wp + ib[q] * BLD + (c & ~1));
-          const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c]
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc[q], 0, 0, 0);   // K_i . W_j
-        }
-      }
+          const double li = lam[min(ib[q], nact - 1)];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double li = lam[min(ib[q], nact - 1)];
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const double Lij = partial ? (lj[rg] + li - li * lj[rg]) : 1.0;
-          pv[h + q][rg] -= Lij * acc[q][rg];
+          for (int rg = 0; rg < 4; rg++) {
+            const double Lij = partial ? (lj[rg] + li - li * lj[rg]) : 1.0;
+            pv[h + q][rg] -= Lij * acc[q][rg];
+          }
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < TPI; q++) {                       // (every store after the last wait on a load)
+    for (int q = 0; q < TPI; q++) {
       const int i = 16 * (ti0 + q) + lr;
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int j = j0t + lk + 4 * rg;
         if (ti0 + q < nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
       }
+    }
+    PASS_STAMP();
+  };
+  PASS_STAMP();
+  int t = draw();
+  if (t < NU) {
+    double pvA[TPI][4], pvB[TPI][4], ljA[4], ljB[4];
+    int tjA, tiA, tjB, tiB;
+    issue(t, pvA, ljA, tjA, tiA);
+    PASS_STAMP();
+    for (;;) {                                            // (the issue is unconditional -- past the last unit it reloads that one and
+      t = draw();                                         //  drops it: a branch around it makes the compiler wait for BOTH sets)
+      issue(min(t, NU - 1), pvB, ljB, tjB, tiB);
+      PASS_STAMP();
+      finish(pvA, ljA, tjA, tiA);
+      if (t >= NU) break;
+      t = draw();
+      issue(min(t, NU - 1), pvA, ljA, tjA, tiA);
+      finish(pvB, ljB, tjB, tiB);
+      if (t >= NU) break;
+    }
+  }
+  // ---- the diagonal tiles: K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j
+  for (; t < NU + nt; t = draw()) {
+    const int j0t = 16 * (t - NU), i = j0t + lr;
+    double pv[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) pv[rg] = P[min(i, nact - 1) + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    for (int sk = 0; sk < ksteps; sk++) {
+      const int c = 4 * sk + lk;
+      const double2 wi = *reinterpret_cast<const double2*>(Wp + i * BLD + (c & ~1));
+      const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
+      const double wic = (c & 1) ? wi.y : wi.x;
+      const double kic = wi.x * sv.x + wi.y * sv.y;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wic, kic, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kic, wic, acc2, 0, 0, 0);
+    }
+    const double li = lam[min(i, nact - 1)];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int j = j0t + lk + 4 * rg;
+      const double lj = lam[min(j, nact - 1)];
+      const double Lij = partial ? (lj + li - li * lj) : 1.0;
+      const double av = (i < j) ? acc2[rg] : acc[rg];
+      if (i < nact && j < nact) P[i + (long)j * ld] = pv[rg] - Lij * av;
     }
   }
 }
@@ -878,7 +915,12 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
     PSV_STAMP(2);
     // prev's pass over P (psv_pass above); the units are drawn from a counter, so the waves that come late (the three with feature
     // lanes, the one with the body lane, the service wave) take what is left.  (The rho-rho diagonal is kept in LDS: written at the end.)
+#ifdef VIEKF_STAMPS
+    if (Gp > 0) psv_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, partial, lane, flg + 2,
+                                 (b == 0 && stamp_iter == 1) ? reinterpret_cast<unsigned long long*>(a.ws) + 16 * wave + 8 : nullptr);
+#else
     if (Gp > 0) psv_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, partial, lane, flg + 2);
+#endif
     PSV_STAMP(6);
     __syncthreads();                                       // prev's pass is done; cur's mail / ctab / cbuf are ready
     PSV_STAMP(3);
