@@ -34,7 +34,8 @@ for w in range(8):
         print("wave %d: preload barrier -> D done %6d | pass %6d | wait %6d || A %6d | C %6d" % (w, d(0, 1) if t[q + 1] else 0, d(2, 6), d(6, 3), d(3, 4), d(4, 5)))
     else:
         print("wave 7: preload + pending corrections %6d | chain %6d | pass %6d | wait %6d || A %6d | C %6d" % (d(0, 7), d(7, 2), d(2, 6), d(6, 3), d(3, 4), d(4, 5)))
-print("inside the pass (first marks of each wave): entry | issue A | draw + issue B | k-loop A | epilogue A | stores A | draw + issue A' | k-loop B")
+print("inside the pass (first marks of each wave; A, B = the two register sets):")
+print("        issue A | draw | issue B | k-loop A | row scale A | stores A | draw | issue A' | k-loop B | row scale B | stores B | draw | issue B' | k-loop A' | row scale A'")
 for w in range(8):
-    q = 16 * w + 8
-    print("wave %d: " % w + " ".join("%6d" % int(t[q + i + 1] - t[q + i]) for i in range(7)))
+    q = 128 + 16 * w
+    print("wave %d: " % w + " ".join("%6d" % int(t[q + i + 1] - t[q + i]) for i in range(15)))

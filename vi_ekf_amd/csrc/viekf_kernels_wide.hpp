@@ -411,10 +411,10 @@ __device__ __forceinline__ void psv_pass(double* __restrict__ P, int ld, int nac
   const int lr = lane & 15, lk = lane >> 4;
   const int ksteps = (2 * Gn + 3) >> 2;                   // (columns past 2 Gn are zero)
 #ifdef VIEKF_STAMPS
-  int sn = 0;                                             // diagnostic build: the first eight marks of this wave's pass
+  int sn = 0;                                             // diagnostic build: the first sixteen marks of this wave's pass
 #define PASS_STAMP()                                                                      \
   do {                                                                                    \
-    if (st && sn < 8) {                                                                   \
+    if (st && sn < 16) {                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                  \
       if (lane == 0) st[sn] = __builtin_amdgcn_s_memtime();                               \
       __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -432,10 +432,8 @@ __device__ __forceinline__ void psv_pass(double* __restrict__ P, int ld, int nac
     if (lane == 0) t = atomicAdd(ticket, 1);
     return __builtin_amdgcn_readfirstlane(t);
   };
-  // ---- a unit strictly below the diagonal: column block tj, tiles ti0 .. ti0 + 7.  Software-pipelined over two register sets: the
-  // 32 loads of the NEXT unit are issued before the matrix-core work of the current one (a wave used to wait out the whole memory
-  // latency of its unit with nothing else to do: a quarter of its pass time)
-  auto issue = [&](int t, double (&pv)[TPI][4], double (&lj)[4], int& tj, int& ti0) {
+  // ---- a unit strictly below the diagonal: column block tj, tiles ti0 .. ti0 + 3
+  auto decode = [&](int t, int& tj, int& ti0) {
     int rest = t;
     for (tj = 0; tj < nt; tj++) {
       const int nu = (nt - 1 - tj + TPI - 1) / TPI;       // units of this column block (rows tj + 1 .. nt - 1)
@@ -443,78 +441,115 @@ __device__ __forceinline__ void psv_pass(double* __restrict__ P, int ld, int nac
       rest -= nu;
     }
     ti0 = tj + 1 + TPI * rest;
-    const int j0t = 16 * tj;
-#pragma unroll
-    for (int q = 0; q < TPI; q++) {                       // (clamped, unconditional loads: the 32 of a unit in flight together)
-      const int i = min(16 * (ti0 + q) + lr, nact - 1);
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) pv[q][rg] = P[i + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) lj[rg] = lam[min(j0t + lk + 4 * rg, nact - 1)];
   };
-  auto finish = [&](double (&pv)[TPI][4], const double (&lj)[4], int tj, int ti0) {
+  // the matrix-core work of a unit and the Lambda scaling: pv -= Lambda o (K_I . W_J^T)
+  auto compute = [&](double (&pv)[TPI][4], int tj, int ti0) {
     const int j0t = 16 * tj;
+    v4f64 acc[4];
 #pragma unroll
-    for (int h = 0; h < TPI; h += 4) {
-      if (h == 0 || ti0 + h < nt) {                        // (the first four tiles of a unit always exist)
-        v4f64 acc[4];
+    for (int q = 0; q < 4; q++) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+    int ib[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
-        int ib[4];
+    for (int q = 0; q < 4; q++) ib[q] = min(16 * (ti0 + q), 16 * (nt - 1)) + lr;   // (a tile past the end redoes the last one)
+    for (int sk = 0; sk < ksteps; sk++) {                  // (two waves of a SIMD in this loop at once are bound by the matrix core:
+      const int c = 4 * sk + lk;                           //  reading the next k-step's operands ahead gained nothing, r04)
+      const double wjc = Wp[(j0t + lr) * BLD + c];         // this lane's contraction index: column c of pair c >> 1
+      const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
 #pragma unroll
-        for (int q = 0; q < 4; q++) ib[q] = min(16 * (ti0 + h + q), 16 * (nt - 1)) + lr;   // (a tile past the end redoes the last one: discarded)
-        for (int sk = 0; sk < ksteps; sk++) {
-          const int c = 4 * sk + lk;                         // this lane's contraction index: column c of pair c >> 1
-          const double wjc = Wp[(j0t + lr) * BLD + c];
-          const double2 sv = *reinterpret_cast<const double2*>(SiL + 4 * (c >> 1) + 2 * (c & 1));
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const double2 wi = *reinterpret_cast<const double2*>(Wp + ib[q] * BLD + (c & ~1));
-            const double kic = wi.x * sv.x + wi.y * sv.y;    // K[i][c]
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc[q], 0, 0, 0);   // K_i . W_j
-          }
-        }
-        PASS_STAMP();
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const double li = lam[min(ib[q], nact - 1)];
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            const double Lij = partial ? (lj[rg] + li - li * lj[rg]) : 1.0;
-            pv[h + q][rg] -= Lij * acc[q][rg];
-          }
-        }
+      for (int q = 0; q < 4; q++) {
+        const double2 wi = *reinterpret_cast<const double2*>(Wp + ib[q] * BLD + (c & ~1));
+        const double kic = wi.x * sv.x + wi.y * sv.y;      // K[i][c]
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(wjc, kic, acc[q], 0, 0, 0);   // K_i . W_j
       }
     }
+    PASS_STAMP();
+    double lj[4];
 #pragma unroll
-    for (int q = 0; q < TPI; q++) {
-      const int i = 16 * (ti0 + q) + lr;
+    for (int rg = 0; rg < 4; rg++) lj[rg] = lam[min(j0t + lk + 4 * rg, nact - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double li = lam[min(ib[q], nact - 1)];
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        const int j = j0t + lk + 4 * rg;
-        if (ti0 + q < nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
+        const double Lij = partial ? (lj[rg] + li - li * lj[rg]) : 1.0;
+        pv[q][rg] -= Lij * acc[q][rg];
       }
     }
     PASS_STAMP();
   };
   PASS_STAMP();
   int t = draw();
-  if (t < NU) {
-    double pvA[TPI][4], pvB[TPI][4], ljA[4], ljB[4];
-    int tjA, tiA, tjB, tiB;
-    issue(t, pvA, ljA, tjA, tiA);
-    PASS_STAMP();
-    for (;;) {                                            // (the issue is unconditional -- past the last unit it reloads that one and
-      t = draw();                                         //  drops it: a branch around it makes the compiler wait for BOTH sets)
-      issue(min(t, NU - 1), pvB, ljB, tjB, tiB);
+  if (ld >= 16 * nt) {
+    // Padded columns (the streaming family's layout, viekf_capi.hip: ld a multiple of 16): every row 16 ti + lr < 16 nt of a column
+    // below n exists in memory, and the panel rows nact .. 16 nt - 1 are ZERO (written once per launch), so the ragged last tile row
+    // needs neither clamps nor predicates -- the update of its rows past nact is  P -= Lambda o (0 . W^T): the value read is written
+    // back.  A unit is then 16 loads and 16 stores at 32-bit offsets from the workgroup's base (the address arithmetic and the
+    // predicates were a quarter of a unit's time), and the loop is software-pipelined over two register sets: the loads of the NEXT
+    // unit are issued before the matrix-core work of the current one.  (A unit of fewer than four tiles redoes its last tile in the
+    // spare slots: the same values stored twice.)  Nothing branches between a load and its use: a join makes the compiler's
+    // wait-count bookkeeping wait for BOTH sets.
+    auto offs = [&](int tj, int ti0, int q, int rg) {
+      return (unsigned)(min(16 * (ti0 + q), 16 * (nt - 1)) + lr) + (unsigned)(16 * tj + lk + 4 * rg) * (unsigned)ld;
+    };
+    auto issue = [&](int tt, double (&pv)[TPI][4], int& tj, int& ti0) {
+      decode(tt, tj, ti0);
+#pragma unroll
+      for (int q = 0; q < TPI; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) pv[q][rg] = P[offs(tj, ti0, q, rg)];
+    };
+    auto store = [&](const double (&pv)[TPI][4], int tj, int ti0) {
+#pragma unroll
+      for (int q = 0; q < TPI; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) P[offs(tj, ti0, q, rg)] = pv[q][rg];
       PASS_STAMP();
-      finish(pvA, ljA, tjA, tiA);
-      if (t >= NU) break;
-      t = draw();
-      issue(min(t, NU - 1), pvA, ljA, tjA, tiA);
-      finish(pvB, ljB, tjB, tiB);
-      if (t >= NU) break;
+    };
+    if (t < NU) {
+      double pvA[TPI][4], pvB[TPI][4];
+      int tjA, tiA, tjB, tiB;
+      issue(t, pvA, tjA, tiA);
+      PASS_STAMP();
+      for (;;) {                                          // (the issue is unconditional -- past the last unit it reloads that one and
+        t = draw();                                       //  drops it)
+        PASS_STAMP();
+        issue(min(t, NU - 1), pvB, tjB, tiB);
+        PASS_STAMP();
+        compute(pvA, tjA, tiA);
+        store(pvA, tjA, tiA);
+        if (t >= NU) break;
+        t = draw();
+        PASS_STAMP();
+        issue(min(t, NU - 1), pvA, tjA, tiA);
+        PASS_STAMP();
+        compute(pvB, tjB, tiB);
+        store(pvB, tjB, tiB);
+        if (t >= NU) break;
+      }
+    }
+  } else {
+    // dense columns (the on-chip family's layout, when this kernel is forced at a small N): clamped loads, predicated stores
+    for (; t < NU; t = draw()) {
+      int tj, ti0;
+      decode(t, tj, ti0);
+      const int j0t = 16 * tj;
+      double pv[TPI][4];
+#pragma unroll
+      for (int q = 0; q < TPI; q++) {
+        const int i = min(16 * (ti0 + q) + lr, nact - 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) pv[q][rg] = P[i + (long)min(j0t + lk + 4 * rg, nact - 1) * ld];
+      }
+      compute(pv, tj, ti0);
+#pragma unroll
+      for (int q = 0; q < TPI; q++) {
+        const int i = 16 * (ti0 + q) + lr;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int j = j0t + lk + 4 * rg;
+          if (ti0 + q < nt && i < nact && j < nact) P[i + (long)j * ld] = pv[q][rg];
+        }
+      }
     }
   }
   // ---- the diagonal tiles: K_i . W_j for i >= j and the mirror expression K_j . W_i (same products, same order) for i < j
@@ -597,6 +632,7 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
   for (int i = tid; i < xZ + 5 * len; i += T) xs[i] = xg[i];
   for (int i = tid; i < n; i += T) lam[i] = a.lambda[i];
   for (int f = tid; f < len; f += T) diag[f] = P[(16 + 3 * f + 2) + (long)(16 + 3 * f + 2) * ld];
+  for (int i = nact * BLD + tid; i < ((n + 15) & ~15) * BLD; i += T) Wp[i] = 0.0;   // the panel rows past the active ones stay zero (psv_pass)
   __syncthreads();
 
   // fix_depth (vi_ekf_helper.cpp:128-156) of one feature: rho and its P(rho, rho), both in the caller's registers
@@ -917,7 +953,7 @@ __global__ __launch_bounds__(T) void k_update_feat_panelsvc(StreamArgs a, const 
     // lanes, the one with the body lane, the service wave) take what is left.  (The rho-rho diagonal is kept in LDS: written at the end.)
 #ifdef VIEKF_STAMPS
     if (Gp > 0) psv_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, partial, lane, flg + 2,
-                                 (b == 0 && stamp_iter == 1) ? reinterpret_cast<unsigned long long*>(a.ws) + 16 * wave + 8 : nullptr);
+                                 (b == 0 && stamp_iter == 1) ? reinterpret_cast<unsigned long long*>(a.ws) + 128 + 16 * wave : nullptr);
 #else
     if (Gp > 0) psv_pass<T, BLD>(P, ld, nact, Gp, Wp, SiL, lam, partial, lane, flg + 2);
 #endif
