@@ -337,6 +337,38 @@ def test_wide_p_streaming_family(N, M, prop):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,nfeat", [(100, 70), (150, 101), (150, 37)])
+def test_wide_p_partially_filled(N, nfeat):
+    """fewer tracked features than slots at wide P (len_features < NUM_FEATURES, include/vi_ekf.h:205-214: everything past the active
+    16 + 3 len block stays as it was set up): the look-ahead kernel's pass runs the ragged last tile row without clamps or predicates on padded
+    columns -- its rows past the active block must come back as they were.  x and the WHOLE n x n covariance against the oracle"""
+    B, steps = 2, 2
+    sc = scene.make_scene(B, N, steps, seed=700 + N + nfeat)
+    keep = [np.flatnonzero(sc["slot"][b] < nfeat) for b in range(B)]
+    M = min(len(k) for k in keep)
+    slot = np.stack([sc["slot"][b][keep[b][:M]] for b in range(B)]).astype(np.int32)
+    z = np.stack([np.stack([sc["z"][s][b][keep[b][:M]] for b in range(B)]) for s in range(steps)])
+    fs = []
+    for b in range(B):
+        f = orc.OracleFilter(N).init(**oracle_params(sc["params"]))
+        for i in range(nfeat):
+            f.init_feature(sc["pix"][b, i], i)
+        fs.append(f)
+    g = make_gpu(sc, B, N, nfeat=nfeat, kernel=1)
+    assert "k_update_feat_panelsvc" in g.describe(), g.describe()
+    for s in range(steps):
+        res = g.step(sc["u"][s], sc["dt"], z[s], slot, sc["R"])
+        for b in range(B):
+            ref = fs[b].run_steps(sc["u"][s, b][None], sc["dt"][b], z[s, b][None], slot[b], sc["R"])[0]
+            assert (res[b] == ref).all()
+    assert_close(g.get_state(), np.stack([f.x for f in fs]), "x")
+    P, Pr = g.get_covariance(), np.stack([f.P for f in fs])
+    assert_close(P, Pr, "P")
+    na = 16 + 3 * nfeat
+    assert (P[:, na:, :] == Pr[:, na:, :]).all() and (P[:, :, na:] == Pr[:, :, na:]).all()    # (untouched: bit for bit)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,M,kernel", [(12, 70, 2), (12, 70, 1), (50, 130, 2), (66, 90, 2), (50, 130, 3), (50, 130, 5)])
 def test_more_measurements_than_one_launch_holds(N, M, kernel):
     """M > 64 measurements per step (the fused kernel takes 64 per launch: vi_ekf_amd chunks, P makes one extra HBM round
