@@ -10,6 +10,10 @@
 #ifndef LDV
 #define LDV 466
 #endif
+#ifndef TPV
+#define TPV 4
+#endif
+constexpr int TP = TPV;                                   // tiles per unit (-DTPV=8: 1 KB contiguous per column)
 constexpr int N = 466, LD = LDV, NT = (N + 15) / 16;      // the N_feat = 150 covariance (-DLDV=480: columns padded to whole 128-B lines)
 
 // MODE 0: tile units, load all -> update -> store all.  MODE 1: the same, software-pipelined over two register sets.
@@ -23,7 +27,7 @@ __global__ __launch_bounds__(512) void k_rmw(double* base, int passes, int* tick
   int* ticket = reinterpret_cast<int*>(smem);
   if (threadIdx.x == 0) *ticket = 0;
   __syncthreads();
-  constexpr int NU = NT * (NT - 1) / 2 / 4 + NT / 4;       // units of four tiles in the lower triangle (about)
+  constexpr int NU = (NT * (NT - 1) / 2 / 4 + NT / 4) * 4 / TP;   // units of TP tiles in the lower triangle (about)
   for (int pass = 0; pass < passes; pass++) {
     auto draw = [&]() {
       int t = 0;
@@ -33,49 +37,49 @@ __global__ __launch_bounds__(512) void k_rmw(double* base, int passes, int* tick
     if (MODE == 0 || MODE == 1) {
       auto addr = [&](int u, int q, int rg) {
         // unit u -> column block tj, tile rows ti0 .. ti0 + 3 (disjoint units; the triangle's shape does not matter here)
-        const int tj = u % NT, ti0 = 4 * (u / NT);
+        const int tj = u % NT, ti0 = TP * (u / NT);
         const int i = min(16 * (ti0 + q) + lr, N - 1), j = min(16 * tj + lk + 4 * rg, N - 1);
         return P + i + (long)j * LD;
       };
       if (MODE == 0) {
         for (int u = draw(); u < NU; u = draw()) {
-          double pv[4][4];
+          double pv[TP][4];
 #pragma unroll
-          for (int q = 0; q < 4; q++)
+          for (int q = 0; q < TP; q++)
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) pv[q][rg] = *addr(u, q, rg);
 #pragma unroll
-          for (int q = 0; q < 4; q++)
+          for (int q = 0; q < TP; q++)
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) *addr(u, q, rg) = pv[q][rg] * 1.0000001 + 1.0;
         }
       } else {
         int u = draw();
         if (u < NU) {
-          double pa[4][4], pb[4][4];
+          double pa[TP][4], pb[TP][4];
           int ua = u, ub;
 #pragma unroll
-          for (int q = 0; q < 4; q++)
+          for (int q = 0; q < TP; q++)
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) pa[q][rg] = *addr(ua, q, rg);
           for (;;) {
             u = draw(); ub = min(u, NU - 1);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < TP; q++)
 #pragma unroll
               for (int rg = 0; rg < 4; rg++) pb[q][rg] = *addr(ub, q, rg);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < TP; q++)
 #pragma unroll
               for (int rg = 0; rg < 4; rg++) *addr(ua, q, rg) = pa[q][rg] * 1.0000001 + 1.0;
             if (u >= NU) break;
             u = draw(); ua = min(u, NU - 1);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < TP; q++)
 #pragma unroll
               for (int rg = 0; rg < 4; rg++) pa[q][rg] = *addr(ua, q, rg);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < TP; q++)
 #pragma unroll
               for (int rg = 0; rg < 4; rg++) *addr(ub, q, rg) = pb[q][rg] * 1.0000001 + 1.0;
             if (u >= NU) break;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(512) void k_rmw(double* base, int passes, int* tick
       }
     } else if (MODE == 2) {
       for (int u = draw(); u < NU; u = draw()) {
-        double* p = P + (long)u * 1024 + lane;
+        double* p = P + (long)u * 1024 + lane;   // (8 KB units)
         double pv[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) pv[k] = p[64 * k];
@@ -110,7 +114,7 @@ template <int MODE>
 static void run(double* buf, int blocks, int passes, const char* what) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  constexpr int NU = NT * (NT - 1) / 2 / 4 + NT / 4;
+  constexpr int NU = (NT * (NT - 1) / 2 / 4 + NT / 4) * 4 / TP;
   const size_t lds = 120 * 1024;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_rmw<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   k_rmw<MODE><<<blocks, 512, lds>>>(buf, 2, nullptr);
@@ -121,7 +125,7 @@ static void run(double* buf, int blocks, int passes, const char* what) {
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  const double bytes = 2.0 * 8192.0 * NU * passes * blocks;   // read + write, 8 KB per unit
+  const double bytes = 2.0 * 2048.0 * TP * NU * passes * blocks;   // read + write, 2 KB per tile
   const int rounds = (blocks + 255) / 256, cus = blocks < 256 ? blocks : 256;
   printf("%-44s %4d workgroups: %7.3f ms  %7.1f GB/s  = %5.1f GB/s per active CU (%d round(s))\n", what, blocks, ms, bytes / ms * 1e-6,
          bytes / ms * 1e-6 / cus, rounds);
