@@ -540,7 +540,7 @@ def main():
             import seq_bench
             pf = 0 if args.no_cpu_baseline else 5      # frames flown against oracle/seq_oracle.SeqOracle before the timed run
             seq_cad = {"shared_clock": seq_bench.run(B, N, False, 40, parity_frames=pf),
-                       "independent_clocks": seq_bench.run(B, N, True, 5, parity_frames=pf)}
+                       "independent_clocks": seq_bench.run(B, N, True, 24, parity_frames=pf)}
             if cadence is not None:
                 seq_cad["shared_vs_raw_cadence"] = seq_cad["shared_clock"]["imu_steps_per_s"] / cadence["imu_steps_per_s"]
         except SystemExit:
