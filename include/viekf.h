@@ -225,7 +225,8 @@ int viekf_batch_get_cov_block(viekf_batch *b, int32_t row0, int32_t col0, int32_
 
 /* Bounded device-side history for delayed measurements (the reference rewinds its 250-deep ring of (x,P,t),
  * include/vi_ekf.h:50,156-160, src/vi_ekf/vi_ekf_meas.cpp:45-63).  viekf_batch_history_resize allocates `depth`
- * snapshot slots of the whole batch (depth * batch * (8 n ld + 8 nx) bytes: choose it, the reference's 250 would be
+ * snapshot slots of the whole batch (depth * batch * (8 n ld + 8 nx) bytes, ld = n rounded up to even for
+ * num_features <= 77 and to a multiple of 16 above: choose it, the reference's 250 would be
  * 55 MB per filter at N=50); snapshot copies the live (x, P, len) into a slot, restore copies it back. */
 int viekf_batch_history_resize(viekf_batch *b, int32_t depth);
 int viekf_batch_snapshot(viekf_batch *b, int32_t slot);
