@@ -11,7 +11,7 @@ from tests.test_gpu_parity import assert_close, oracle_params
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N", [6, 12])
+@pytest.mark.parametrize("N", [6, 12, 80])
 def test_keep_features_matches_clear_feature(N):
     B = 3
     sc = scene.make_scene(B, N, 3, seed=80 + N)
@@ -74,7 +74,7 @@ def test_snapshot_restore_replays_identically():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [5, 50])
+@pytest.mark.parametrize("N", [5, 50, 80])
 def test_keyframe_reset_matches_oracle(N):
     """device keyframe reset (state, N P N^T, edge) vs the oracle's restatement of vi_ekf_kfr.cpp:56-157"""
     import vi_ekf_amd as v
@@ -110,7 +110,7 @@ def test_keyframe_reset_matches_oracle(N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0), (50, 3), (50, 5)])
+@pytest.mark.parametrize("N,kernel", [(12, 0), (12, 1), (50, 0), (85, 0), (50, 3), (50, 5)])
 def test_propagate_to_ring_slot_equals_in_place(N, kernel):
     """zero-copy history: propagate_to writes the next ring slot and selects it; the old slot keeps the old state"""
     import ctypes as C
