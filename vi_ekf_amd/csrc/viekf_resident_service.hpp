@@ -207,6 +207,8 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     o.kA = kv[0]; o.wA = wv[0]; o.kB = kv[1]; o.wB = wv[1]; o.kC = kv[2]; o.bad = bad;
     o.oA = isfeat ? kv[0] : wv[0]; o.oB = isfeat ? kv[1] : wv[1]; o.oC = isfeat ? kv[2] : wv[2];
   };
+  // (MERGE: next_rows and the state correction in one basic block -- see the update loop)
+  constexpr bool MERGE = (T != 256);
   // This lane's rows of the NEXT measurement's column pair: published by the worker waves one phase ago (buffer `rb`), as they
   // stood BEFORE the update being swept in this phase -- which is applied here (`swept`; gains Kc / Wc, this lane's own K rows
   // k3), with the workers' expression  p - Lambda (K . W):  feature rows i take K_i (own) and W of the column's feature,
@@ -222,7 +224,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const double* raw = S.Praw + rb * 2 * n;
     double2 st[3];
     st[0] = lds_ld2(raw + 2 * ridv[0]);      // (P[i][j0], P[i][j0+1]) before the update
-    if (three) { st[1] = lds_ld2(raw + 2 * ridv[1]); st[2] = lds_ld2(raw + 2 * ridv[2]); }
+    if (MERGE || three) { st[1] = lds_ld2(raw + 2 * ridv[1]); st[2] = lds_ld2(raw + 2 * ridv[2]); }   // (MERGE: a lane with ONE row has it three times -- no branch)
     double2 ua, ub;                           // the uniform operands for columns j0, j0+1
     if (holds(slot)) {                        // (wave-uniform) the column feature's rows are in this wave's registers
       const int sl = lane_of(slot);
@@ -247,7 +249,7 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
       o[u] = make_double2(r0, r1);
     };
     one(0);
-    if (three) { one(1); one(2); }
+    if (MERGE || three) { one(1); one(2); }
     else { o[1] = o[0]; o[2] = o[0]; }
     if (isfeat && fid == slot) o[1].x = o[0].y;   // the measured feature's own zeta block: lower = upper, as the workers keep it
   };
@@ -305,42 +307,96 @@ __device__ __forceinline__ void res_service(const StreamArgs& a, const ResShared
     const bool bad = crow.bad != 0 || (ROLE != 0 && sm[44 + cnt % 3 + (ROLE == 2 ? 0 : 8)] != 0.0);
     const double r0 = cur.r0, r1 = cur.r1;
     double2 prn[3] = {};
-    if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !RES_ABLATE(S, 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
-    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
-    RES_MARK("service.correction");
-    // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
-    const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
-    const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
-    const double dv1 = (lam1 * kB.x) * r0 + (lam1 * kB.y) * r1;
-    const double dv2 = (lam2 * kC.x) * r0 + (lam2 * kC.y) * r1;
-    const double kw[8] = {wA.x, wA.y, kA.x, kA.y, wB.x, wB.y, kB.x, kB.y};   // (w0,w1,k0,k1) of rows 0,1
-    // rotation vector of the correction: bearing  T_zeta [d0 d1],  attitude  [d0 d1 d2]
-    double v[3];
-    v[0] = isatt ? dv0 : (f1[0] * dv0 + f2[0] * dv1);
-    v[1] = isatt ? dv1 : (f1[1] * dv0 + f2[1] * dv1);
-    v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
-    RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
-    RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
-    const bool corr = !gated && !bad && !RES_ABLATE(S, 2);
-    // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
-    // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
-    if (corr) {
-      double e[4];
-      q_exp_fast(v, e);
-      // e (x) q  and  q (x) e  share every term but the sign of the cross product (src/quat.cpp:304-312)
-      const double ex = sgn * e[1], ey = sgn * e[2], ez = sgn * e[3];
-      const double o0 = e[0] * qn[0] - e[1] * qn[1] - e[2] * qn[2] - e[3] * qn[3];
-      const double o1 = e[0] * qn[1] + qn[0] * e[1] + (ey * qn[3] - ez * qn[2]);
-      const double o2 = e[0] * qn[2] + qn[0] * e[2] + (ez * qn[1] - ex * qn[3]);
-      const double o3 = e[0] * qn[3] + qn[0] * e[3] + (ex * qn[2] - ey * qn[1]);
-      qn[0] = o0; qn[1] = o1; qn[2] = o2; qn[3] = o3;
-      bearing_frame_fast(qn, f1, f2, fz);
-      lin += isfeat ? dv2 : dv0;
-      // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
-      pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
-      pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
-      pf10 = pf01;   // (the workers keep the diagonal blocks exactly symmetric: lower = upper)
-      pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
+    if constexpr (MERGE) {
+      // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
+      const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
+      const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
+      const double dv1 = (lam1 * kB.x) * r0 + (lam1 * kB.y) * r1;
+      const double dv2 = (lam2 * kC.x) * r0 + (lam2 * kC.y) * r1;
+      const double kw[8] = {wA.x, wA.y, kA.x, kA.y, wB.x, wB.y, kB.x, kB.y};   // (w0,w1,k0,k1) of rows 0,1
+      // rotation vector of the correction: bearing  T_zeta [d0 d1],  attitude  [d0 d1 d2]
+      double v[3];
+      v[0] = isatt ? dv0 : (f1[0] * dv0 + f2[0] * dv1);
+      v[1] = isatt ? dv1 : (f1[1] * dv0 + f2[1] * dv1);
+      v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
+      const bool corr = !gated && !bad && !RES_ABLATE(S, 2);
+      // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
+      // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
+      auto correct = [&]() {
+        double e[4];
+        q_exp_fast(v, e);
+        // e (x) q  and  q (x) e  share every term but the sign of the cross product (src/quat.cpp:304-312)
+        const double ex = sgn * e[1], ey = sgn * e[2], ez = sgn * e[3];
+        const double o0 = e[0] * qn[0] - e[1] * qn[1] - e[2] * qn[2] - e[3] * qn[3];
+        const double o1 = e[0] * qn[1] + qn[0] * e[1] + (ey * qn[3] - ez * qn[2]);
+        const double o2 = e[0] * qn[2] + qn[0] * e[2] + (ez * qn[1] - ex * qn[3]);
+        const double o3 = e[0] * qn[3] + qn[0] * e[3] + (ex * qn[2] - ey * qn[1]);
+        qn[0] = o0; qn[1] = o1; qn[2] = o2; qn[3] = o3;
+        bearing_frame_fast(qn, f1, f2, fz);
+        lin += isfeat ? dv2 : dv0;
+        // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
+        pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
+        pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
+        pf10 = pf01;   // (the workers keep the diagonal blocks exactly symmetric: lower = upper)
+        pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
+      };
+      // The next measurement's rows and the state correction need the same inputs (this update's gain and residual) and nothing of
+      // each other: in the common case -- an update that is applied, another measurement after it -- they sit in ONE basic block, so
+      // that the scheduler fills the latencies of the one dependent chain with the other (a branch around either splits the block).
+      // (Worth 1 - 2 % where this wave's chain sets the phase -- one workgroup per CU, the small instances; where the workers do --
+      //  the three-worker-wave instances, two workgroups per CU: the headline -- the longer block costs 0.6 %: A/B on one box, r04.)
+      if (slot_next >= 0 && corr && !RES_ABLATE(S, 1)) {
+        next_rows((cnt + 1) & 1, true, __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
+        correct();
+        RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
+        RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
+        RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
+      } else {
+        if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !RES_ABLATE(S, 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
+        RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
+        RES_MARK("service.correction");
+        RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
+        RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
+        if (corr) correct();
+      }
+    } else {   // (the three-worker-wave instances: the loop as it was -- their step time follows this code's layout to the per cent)
+      if (slot_next >= 0) next_rows((cnt + 1) & 1, !gated && !bad && !RES_ABLATE(S, 1), __builtin_amdgcn_readfirstlane(slot_next), kP, crow, prn);
+      RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 0);
+      RES_MARK("service.correction");
+      // correction lambda o (K r)   (vi_ekf_meas.cpp:249-255)
+      const double lam0 = partial ? lraw[0] : 1.0, lam1 = partial ? lraw[1] : 1.0, lam2 = partial ? lraw[2] : 1.0;
+      const double dv0 = (lam0 * kA.x) * r0 + (lam0 * kA.y) * r1;
+      const double dv1 = (lam1 * kB.x) * r0 + (lam1 * kB.y) * r1;
+      const double dv2 = (lam2 * kC.x) * r0 + (lam2 * kC.y) * r1;
+      const double kw[8] = {wA.x, wA.y, kA.x, kA.y, wB.x, wB.y, kB.x, kB.y};   // (w0,w1,k0,k1) of rows 0,1
+      // rotation vector of the correction: bearing  T_zeta [d0 d1],  attitude  [d0 d1 d2]
+      double v[3];
+      v[0] = isatt ? dv0 : (f1[0] * dv0 + f2[0] * dv1);
+      v[1] = isatt ? dv1 : (f1[1] * dv0 + f2[1] * dv1);
+      v[2] = isatt ? dv2 : (f1[2] * dv0 + f2[2] * dv1);
+      RES_STAMP(S, lane == 0 && it_ < 8, 16 + 4 * it_ + 1);
+      RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 0);
+      const bool corr = !gated && !bad && !RES_ABLATE(S, 2);
+      // x <- x [+] dx  (vi_ekf_helper.cpp:88-98): bearing  exp(T_z d) (x) q ;  attitude  q (x) exp(d) ;  the rest adds.
+      // The corrected quaternion / inverse depth stay in registers for fix_depth and the next prediction.
+      if (corr) {
+        double e[4];
+        q_exp_fast(v, e);
+        // e (x) q  and  q (x) e  share every term but the sign of the cross product (src/quat.cpp:304-312)
+        const double ex = sgn * e[1], ey = sgn * e[2], ez = sgn * e[3];
+        const double o0 = e[0] * qn[0] - e[1] * qn[1] - e[2] * qn[2] - e[3] * qn[3];
+        const double o1 = e[0] * qn[1] + qn[0] * e[1] + (ey * qn[3] - ez * qn[2]);
+        const double o2 = e[0] * qn[2] + qn[0] * e[2] + (ez * qn[1] - ex * qn[3]);
+        const double o3 = e[0] * qn[3] + qn[0] * e[3] + (ex * qn[2] - ey * qn[1]);
+        qn[0] = o0; qn[1] = o1; qn[2] = o2; qn[3] = o3;
+        bearing_frame_fast(qn, f1, f2, fz);
+        lin += isfeat ? dv2 : dv0;
+        // this lane's copy of P_zz follows the sweep:  P_rs -= Lambda_rs (K_r . W_s)   (vi_ekf_meas.cpp:256-257)
+        pf00 = fma(-L00, fma(kw[3], kw[1], kw[2] * kw[0]), pf00);
+        pf01 = fma(-L01, fma(kw[3], kw[5], kw[2] * kw[4]), pf01);
+        pf10 = pf01;   // (the workers keep the diagonal blocks exactly symmetric: lower = upper)
+        pf11 = fma(-L11, fma(kw[7], kw[5], kw[6] * kw[4]), pf11);
+      }
     }
     RES_STAMP(S, lane == 0 && it_ < 8, 128 + 4 * it_ + 1);
     RES_MARK("service.fix_depth");
