@@ -154,7 +154,7 @@ def test_propagate_only_partial_features_and_qx(N, nfeat, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2), (76, 2), (50, 3), (46, 3), (50, 5), (46, 5)])
+@pytest.mark.parametrize("N,kernel", [(4, 0), (9, 0), (9, 1), (20, 1), (20, 2), (53, 2), (70, 2), (76, 2), (100, 0), (50, 3), (46, 3), (50, 5), (46, 5)])
 def test_update_gating_nan_invalid_and_full_update(N, kernel):
     """result codes: gated outlier, NaN pixel, out-of-range slot, skipped; Joseph-form (non-partial) update; both kernel
     families (the grouped streaming update has its own gate / skip paths inside a group)"""
@@ -195,7 +195,7 @@ def test_update_gating_nan_invalid_and_full_update(N, kernel):
     assert_close(g.get_covariance(), np.stack([f.P for f in fs]), "P")
 
 
-@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2), (68, 2), (50, 3), (47, 3), (50, 5)])
+@pytest.mark.parametrize("N,kernel", [(6, 1), (6, 2), (24, 1), (24, 2), (56, 2), (68, 2), (90, 0), (50, 3), (47, 3), (50, 5)])
 def test_fix_depth_inside_the_updates(N, kernel):
     """fix_depth after an UPDATE (vi_ekf_meas.cpp:271): features that start just in front of the camera's infinity with a
     large depth variance correlated with the bearing are pushed to rho < 0 by noisy pixels -- the reset, the P(rho,rho) edit and the flag, in the middle
